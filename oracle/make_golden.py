@@ -1,0 +1,355 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.pt by running the REFERENCE's own modules on CPU.
+
+Run by hand in the build container (the only place /root/reference exists):
+
+    python -m oracle.make_golden [ops toy pipe real_block real_fwd]
+
+Inputs and weights come from longlive_amd.synth (integer counter hash), so only seeds + outputs are
+stored and any host / the MI355X can regenerate bit-identical inputs without the reference.
+The reference draws re-noise with torch.randn_like (pipeline/causal_inference.py:175); while a pipeline
+golden is generated that call is answered from the same counter hash (`_HashRandn`) so that the draw is
+reproducible elsewhere.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from longlive_amd import synth
+from oracle.ref_import import load_pipelines
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def _save(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    p = os.path.join(OUT, name)
+    torch.save(obj, p)
+    print(f"wrote {p}  ({os.path.getsize(p) / 1e6:.2f} MB)")
+
+
+class _HashRandn:
+    """Replacement for torch.randn_like inside reference pipelines: call i returns hash_normal(seed, 'renoise.i')."""
+
+    def __init__(self, seed):
+        self.seed, self.i = seed, 0
+
+    def __call__(self, like, **kw):
+        x = synth.hash_normal(self.seed, f"renoise.{self.i}", tuple(like.shape)).to(like.dtype)
+        self.i += 1
+        return x
+
+
+def build_ref_model(ns, cfg: synth.WanConfig, sd, frame_seqlen):
+    M = ns.causal_model.CausalWanModel(
+        model_type="t2v", patch_size=cfg.patch_size, text_len=cfg.text_len, in_dim=cfg.in_dim, dim=cfg.dim,
+        ffn_dim=cfg.ffn_dim, freq_dim=cfg.freq_dim, text_dim=cfg.text_dim, out_dim=cfg.out_dim,
+        num_heads=cfg.num_heads, num_layers=cfg.num_layers, local_attn_size=cfg.local_attn_size,
+        sink_size=cfg.sink_size, qk_norm=True, cross_attn_norm=True, eps=cfg.eps)
+    missing = M.load_state_dict(sd, strict=True)
+    M = M.to(torch.bfloat16).eval()
+    # what CausalInferencePipeline._set_all_modules_max_attention_size does (causal_inference.py:295-329)
+    tgt = 32760 if cfg.local_attn_size == -1 else cfg.local_attn_size * frame_seqlen
+    M.max_attention_size = tgt
+    for m in M.modules():
+        if hasattr(m, "max_attention_size"):
+            m.max_attention_size = tgt
+    M.local_attn_size = cfg.local_attn_size
+    return M
+
+
+def build_ref_wrapper(ns, model, shift=5.0):
+    W = ns.wan_wrapper.WanDiffusionWrapper
+    g = W.__new__(W)
+    nn.Module.__init__(g)
+    g.model = model
+    g.uniform_timestep = False
+    g.scheduler = ns.scheduler.FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
+    g.scheduler.set_timesteps(1000, training=True)
+    g.seq_len = 32760
+    g.post_init()
+    return g
+
+
+def ref_kv_cache(B, S, L, n, d):
+    return [dict(k=torch.zeros(B, S, n, d, dtype=torch.bfloat16), v=torch.zeros(B, S, n, d, dtype=torch.bfloat16),
+                 global_end_index=torch.tensor([0]), local_end_index=torch.tensor([0])) for _ in range(L)]
+
+
+def ref_ca_cache(B, T, L, n, d):
+    return [dict(k=torch.zeros(B, T, n, d, dtype=torch.bfloat16), v=torch.zeros(B, T, n, d, dtype=torch.bfloat16),
+                 is_init=False) for _ in range(L)]
+
+
+# --------------------------------------------------------------------------------------------
+def gen_ops(ns):
+    g = {}
+    bf = torch.bfloat16
+    dim, eps = 256, 1e-6
+    x = (synth.hash_normal(11, "ops.x", (2, 48, dim)) * 1.7 + 0.3).to(bf)
+    w = (1 + 0.1 * synth.hash_normal(11, "ops.w", (dim,))).to(bf)
+    b = (0.1 * synth.hash_normal(11, "ops.b", (dim,))).to(bf)
+    rn = ns.model.WanRMSNorm(dim, eps=eps); rn.weight.data = w.clone(); rn = rn.to(bf)
+    g["rms_norm"] = rn(x)
+    ln = ns.model.WanLayerNorm(dim, eps); g["layer_norm"] = ln(x)
+    la = ns.model.WanLayerNorm(dim, eps, elementwise_affine=True).to(bf)
+    la.weight.data = w.clone(); la.bias.data = b.clone()
+    g["layer_norm_affine"] = la(x)
+    e = (synth.hash_normal(11, "ops.e", (2, 2, 6, dim)) * 0.5).to(bf)
+    ec = e.chunk(6, dim=2)
+    g["ln_modulate"] = (ln(x).unflatten(1, (2, 24)) * (1 + ec[1]) + ec[0]).flatten(1, 2)   # causal_model.py:445
+    y = (synth.hash_normal(11, "ops.y", (2, 48, dim))).to(bf)
+    g["gate_residual"] = x + (y.unflatten(1, (2, 24)) * ec[2]).flatten(1, 2)               # causal_model.py:456
+    # rope
+    q = synth.hash_normal(11, "ops.q", (2, 48, 2, 128)).to(bf)
+    freqs = torch.cat([ns.model.rope_params(1024, 44), ns.model.rope_params(1024, 42), ns.model.rope_params(1024, 42)], dim=1)
+    grid = torch.tensor([[2, 4, 6], [2, 4, 6]])
+    for sf in (0, 5, 959):
+        g[f"rope_sf{sf}"] = ns.causal_model.causal_rope_apply(q, grid, freqs, start_frame=sf).type_as(q)
+    g["freqs_real"] = torch.view_as_real(freqs).to(torch.float64)[:8].clone()
+    # time embedding sinusoid
+    t = torch.tensor([1000.0, 937.5, 833.3333, 625.0, 0.0, 3.0])
+    g["sinusoid"] = ns.model.sinusoidal_embedding_1d(256, t)
+    # scheduler
+    sch = ns.scheduler.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    g["sigmas"] = sch.sigmas.clone(); g["timesteps"] = sch.timesteps.clone()
+    ts = torch.cat((sch.timesteps, torch.tensor([0.0])))[1000 - torch.tensor([1000, 750, 500, 250])]
+    g["warped_steps"] = ts
+    x0 = synth.hash_normal(11, "ops.x0", (4, 16, 8, 12)).to(bf)
+    nz = synth.hash_normal(11, "ops.nz", (4, 16, 8, 12)).to(bf)
+    g["add_noise"] = sch.add_noise(x0, nz, ts[[1, 2, 3, 3]] * torch.ones(4, dtype=torch.long))
+    wr = build_ref_wrapper(ns, nn.Identity())
+    g["flow_to_x0"] = wr._convert_flow_pred_to_x0(nz, x0, ts)
+    # attention (CPU SDPA fallback, bf16)
+    qa = synth.hash_normal(11, "ops.qa", (1, 40, 2, 128)).to(bf)
+    ka = synth.hash_normal(11, "ops.ka", (1, 72, 2, 128)).to(bf)
+    va = synth.hash_normal(11, "ops.va", (1, 72, 2, 128)).to(bf)
+    g["attention"] = ns.attention.attention(qa, ka, va)
+    _save("ops.pt", g)
+
+
+# --------------------------------------------------------------------------------------------
+def _toy_trace(ns, name, cfg: synth.WanConfig, nfb: int, T: int, B: int, recache_at, steps=(1000.0, 700.0), keep_blocks=(0, 3)):
+    """Drive reference CausalWanModel._forward_inference through the pipeline's call sequence by hand
+    (the reference pipelines hard-code 12x128 heads, so the 2-head toy cannot go through them)."""
+    fs = cfg.frame_seqlen
+    sd = synth.synth_state_dict(cfg, seed=3)
+    M = build_ref_model(ns, cfg, {k: v.float() for k, v in sd.items()}, fs)
+    wr = build_ref_wrapper(ns, M)
+    S = (cfg.local_attn_size if cfg.local_attn_size != -1 else T) * fs
+    kv = ref_kv_cache(B, S, cfg.num_layers, cfg.num_heads, cfg.head_dim)
+    ca = ref_ca_cache(B, cfg.text_len, cfg.num_layers, cfg.num_heads, cfg.head_dim)
+    noise = synth.synth_noise(cfg, T, seed=5, batch=B)
+    prompts = [synth.synth_prompt_embeds(cfg, seed=7 + i, batch=B, valid_tokens=9) for i in range(3)]
+    rnd = _HashRandn(9)
+    out = torch.zeros_like(noise)
+    rec = dict(x0s=[], idx=[], caches={}, cfg=vars(cfg).copy(), nfb=nfb, T=T, B=B,
+               recache_at=dict(recache_at), steps=list(steps))
+    seg, start = 0, 0
+
+    def fwd(x, prompt, tval, cs, sink_recache=False):
+        t = torch.ones([B, x.shape[1]], dtype=torch.float32) * tval
+        flow, x0 = wr(noisy_image_or_video=x, conditional_dict={"prompt_embeds": prompt}, timestep=t,
+                      kv_cache=kv, crossattn_cache=ca, current_start=cs, sink_recache_after_switch=sink_recache)
+        rec["x0s"].append(x0.clone())
+        rec["idx"].append((int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"]),
+                           int(kv[-1]["global_end_index"]), int(kv[-1]["local_end_index"])))
+        return x0
+
+    for blk in range(T // nfb):
+        if start in recache_at:
+            global_sink = recache_at[start]
+            seg += 1
+            if not global_sink:
+                for c in kv:
+                    c["k"].zero_(); c["v"].zero_()
+            for c in ca:
+                c["k"].zero_(); c["v"].zero_(); c["is_init"] = False
+            nre = start if cfg.local_attn_size == -1 else min(cfg.local_attn_size, start)
+            fwd(out[:, start - nre:start], prompts[seg], 0.0, (start - nre) * fs, sink_recache=not global_sink)
+            for c in ca:
+                c["k"].zero_(); c["v"].zero_(); c["is_init"] = False
+            rec["caches"][f"after_recache_{start}"] = [(c["k"].clone(), c["v"].clone()) for c in kv]
+        noisy = noise[:, start:start + nfb]
+        for i, tv in enumerate(steps):
+            x0 = fwd(noisy, prompts[seg], tv, start * fs)
+            if i < len(steps) - 1:
+                noisy = wr.scheduler.add_noise(x0.flatten(0, 1), rnd(x0.flatten(0, 1)),
+                                               steps[i + 1] * torch.ones([B * nfb])).unflatten(0, x0.shape[:2])
+        out[:, start:start + nfb] = x0
+        fwd(x0, prompts[seg], 0.0, start * fs)
+        if blk in keep_blocks or blk == T // nfb - 1:
+            rec["caches"][f"after_block_{blk}"] = [(c["k"].clone(), c["v"].clone()) for c in kv]
+        start += nfb
+    rec["output"] = out
+    _save(name, rec)
+
+
+def gen_toy(ns):
+    _toy_trace(ns, "toy_trace_f1_w3_s1.pt", synth.toy_config(local_attn_size=3, sink_size=1), nfb=1, T=9, B=2,
+               recache_at={5: False, 7: True})
+    _toy_trace(ns, "toy_trace_f2_w5_s2.pt", synth.toy_config(local_attn_size=5, sink_size=2), nfb=2, T=12, B=1,
+               recache_at={8: False})
+    _toy_trace(ns, "toy_trace_f1_w4_s0.pt", synth.toy_config(local_attn_size=4, sink_size=0), nfb=1, T=7, B=1,
+               recache_at={})
+    _toy_trace(ns, "toy_trace_global.pt", synth.toy_config(local_attn_size=-1, sink_size=0), nfb=1, T=4, B=1,
+               recache_at={})
+
+
+# --------------------------------------------------------------------------------------------
+def pipe_cfg():
+    """Real width/heads/ffn/text (the reference pipelines hard-code 12x128 heads), 2 layers, 8x12 latents."""
+    return synth.WanConfig(num_layers=2, lat_h=8, lat_w=12, local_attn_size=12, sink_size=3)
+
+
+def _fake_text_encoder(prompt_table):
+    def enc(text_prompts):
+        return {"prompt_embeds": prompt_table[text_prompts[0]]}
+    return enc
+
+
+class _FakeVAE:
+    def decode_to_pixel(self, x, use_cache=False):
+        return x
+
+
+def gen_pipe(ns):
+    cfg = pipe_cfg()
+    fs = cfg.frame_seqlen
+    sd = synth.synth_state_dict(cfg, seed=21)
+    M = build_ref_model(ns, cfg, {k: v.float() for k, v in sd.items()}, fs)
+    wr = build_ref_wrapper(ns, M)
+    table = {f"p{i}": synth.synth_prompt_embeds(cfg, seed=31 + i) for i in range(3)}
+    args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                           num_frame_per_block=3, context_noise=0, global_sink=True)
+    real_randn_like = torch.randn_like
+    rec = dict(cfg=vars(cfg).copy())
+    try:
+        # config-2-like single prompt, T = 21
+        P = ns.causal_inference.CausalInferencePipeline(args, "cpu", generator=wr, text_encoder=_fake_text_encoder(table),
+                                                        vae=_FakeVAE())
+        P.num_transformer_blocks, P.frame_seq_length = cfg.num_layers, fs
+        noise = synth.synth_noise(cfg, 21, seed=41)
+        torch.randn_like = _HashRandn(43)
+        _, lat = P.inference(noise, ["p0"], return_latents=True)
+        rec["single_T21"] = lat.clone()
+        rec["single_T21_idx"] = (int(P.kv_cache1[0]["global_end_index"]), int(P.kv_cache1[0]["local_end_index"]))
+        # interactive, T = 24, switches 7 / 16, with and without global sink
+        for gs in (False, True):
+            args.global_sink = gs
+            I = ns.interactive.InteractiveCausalInferencePipeline(args, "cpu", generator=wr,
+                                                                  text_encoder=_fake_text_encoder(table), vae=_FakeVAE())
+            I.num_transformer_blocks, I.frame_seq_length = cfg.num_layers, fs
+            noise = synth.synth_noise(cfg, 24, seed=45)
+            torch.randn_like = _HashRandn(47)
+            _, lat = I.inference(noise, text_prompts_list=[["p0"], ["p1"], ["p2"]], switch_frame_indices=[7, 16],
+                                 return_latents=True)
+            rec[f"interactive_T24_gs{int(gs)}"] = lat.clone()
+    finally:
+        torch.randn_like = real_randn_like
+    _save("pipe_w1536_l2.pt", rec)
+
+
+# --------------------------------------------------------------------------------------------
+def synth_kv_fill(cfg, layer, S, fill, seed=61):
+    """Synthetic steady-state cache content: slots [0, fill) ~ N(0,1) keys / 0.5 N(0,1) values."""
+    k = torch.zeros(1, S, cfg.num_heads, cfg.head_dim, dtype=torch.bfloat16)
+    v = torch.zeros_like(k)
+    k[:, :fill] = synth.hash_normal(seed, f"kv.{layer}.k", (1, fill, cfg.num_heads, cfg.head_dim)).to(torch.bfloat16)
+    v[:, :fill] = (0.5 * synth.hash_normal(seed, f"kv.{layer}.v", (1, fill, cfg.num_heads, cfg.head_dim))).to(torch.bfloat16)
+    return k, v
+
+
+def sample_rows(L, n=48):
+    return torch.linspace(0, L - 1, n).round().long()
+
+
+def gen_real_block(ns):
+    """One CausalWanAttentionBlock at the real 1.3B shape, steady state: full 18720-slot cache, roll + insert."""
+    cfg = synth.longlive_1_3b(num_layers=1)
+    fs = cfg.frame_seqlen
+    sd = synth.synth_state_dict(cfg, seed=0, layers=[0])
+    M = build_ref_model(ns, cfg, {k: v.float() for k, v in sd.items()}, fs)
+    blk = M.blocks[0]
+    S = 12 * fs
+    x = synth.hash_normal(71, "blk.x", (1, 3 * fs, cfg.dim)).to(torch.bfloat16)
+    e0 = (0.3 * synth.hash_normal(71, "blk.e0", (1, 3, 6, cfg.dim))).to(torch.bfloat16)
+    ctx = synth.hash_normal(71, "blk.ctx", (1, cfg.text_len, cfg.dim)).to(torch.bfloat16)
+    k, v = synth_kv_fill(cfg, 0, S, S)
+    kv = dict(k=k, v=v, global_end_index=torch.tensor([S]), local_end_index=torch.tensor([S]))
+    ca = dict(k=torch.zeros(1, 512, 12, 128, dtype=torch.bfloat16), v=torch.zeros(1, 512, 12, 128, dtype=torch.bfloat16),
+              is_init=False)
+    grid = torch.tensor([[3, 30, 52]])
+    t0 = time.time()
+    y, (cur_end, local_end, info) = blk(x, e0, torch.tensor([3 * fs]), grid, M.freqs, ctx, None, None,
+                                        kv_cache=kv, crossattn_cache=ca, current_start=S)
+    print(f"real block: {time.time() - t0:.1f}s")
+    M._apply_cache_updates([kv], [(0, (cur_end, local_end, info))])
+    rows = sample_rows(3 * fs)
+    slots = sample_rows(S, 64)
+    _save("real_block.pt", dict(rows=rows, y_rows=y[0, rows].clone(), slots=slots,
+                                k_slots=kv["k"][0, slots].clone(), v_slots=kv["v"][0, slots].clone(),
+                                idx=(int(kv["global_end_index"]), int(kv["local_end_index"])),
+                                y_mean=y.float().mean().item(), y_std=y.float().std().item()))
+
+
+def gen_real_fwd(ns):
+    """Full 30-layer forward at the real shape: block 0 (Lk = 4680), t = 1000, then the same weights at steady
+    state (synthetic full caches, roll path, Lk = 18720), t = 625."""
+    cfg = synth.longlive_1_3b()
+    fs = cfg.frame_seqlen
+    t0 = time.time()
+    sd = synth.synth_state_dict(cfg, seed=0)
+    print(f"weights: {time.time() - t0:.1f}s")
+    M = build_ref_model(ns, cfg, sd, fs)   # load_state_dict copies bf16 -> fp32 params, then .to(bf16): exact
+    wr = build_ref_wrapper(ns, M)
+    S = 12 * fs
+    prompt = synth.synth_prompt_embeds(cfg, seed=1)
+    noise = synth.synth_noise(cfg, 3, seed=0)
+    rec = {}
+    kv = ref_kv_cache(1, S, 30, 12, 128); ca = ref_ca_cache(1, 512, 30, 12, 128)
+    t0 = time.time()
+    flow, x0 = wr(noise, {"prompt_embeds": prompt}, torch.ones(1, 3) * 1000.0, kv_cache=kv, crossattn_cache=ca,
+                  current_start=0)
+    print(f"real fwd block0: {time.time() - t0:.1f}s")
+    rec["flow_block0"] = flow.clone(); rec["x0_block0"] = x0.clone()
+    slots = sample_rows(3 * fs, 32)
+    rec["slots0"] = slots
+    rec["k_l0_block0"] = kv[0]["k"][0, slots].clone(); rec["k_l29_block0"] = kv[29]["k"][0, slots].clone()
+    rec["v_l29_block0"] = kv[29]["v"][0, slots].clone()
+    # steady state
+    for i in range(30):
+        k, v = synth_kv_fill(cfg, i, S, S)
+        kv[i]["k"], kv[i]["v"] = k, v
+        kv[i]["global_end_index"].fill_(S); kv[i]["local_end_index"].fill_(S)
+    t0 = time.time()
+    flow, x0 = wr(noise, {"prompt_embeds": prompt}, torch.ones(1, 3) * 625.0, kv_cache=kv, crossattn_cache=ca,
+                  current_start=S)
+    print(f"real fwd steady: {time.time() - t0:.1f}s")
+    rec["flow_steady"] = flow.clone(); rec["x0_steady"] = x0.clone()
+    slots = sample_rows(S, 64)
+    rec["slots_steady"] = slots
+    rec["k_l29_steady"] = kv[29]["k"][0, slots].clone()
+    rec["idx_steady"] = (int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"]))
+    _save("real_fwd.pt", rec)
+
+
+def main(argv):
+    ns = load_pipelines()
+    todo = argv or ["ops", "toy", "pipe", "real_block", "real_fwd"]
+    for t in todo:
+        t0 = time.time()
+        globals()["gen_" + t](ns)
+        print(f"[{t}] {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
