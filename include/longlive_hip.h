@@ -1,0 +1,132 @@
+/*
+ * longlive_hip.h -- C ABI of liblonglive_hip.so: the MI355X (gfx950) native replacement for the per-frame
+ * denoising hot path of LongLive (reference: kpham-augment/LongLive).
+ *
+ * The reference has no FFI/plugin registry: its "operator API" on this path is the set of PyTorch module calls made
+ * inside CausalWanModel._forward_inference.  Each entry point below replaces one of those call sites (file:line of
+ * the reference is cited per function); the Python host layer (longlive_amd/) mirrors the reference's Python
+ * interface on top of this ABI.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch allocation); bf16 tensors are `uint16_t` bit patterns;
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), never allocates, never syncs;
+ *   - every function returns 0 on success, a negative ll_status otherwise; ll_last_error() gives the message;
+ *   - "rows" are tokens (latent patches); C = model width; token order inside a forward is (frame, h, w).
+ */
+#ifndef LONGLIVE_HIP_H
+#define LONGLIVE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t ll_bf16;
+typedef void* ll_stream;
+
+enum ll_status {
+  LL_OK = 0,
+  LL_ERR_INVALID_ARG = -1,   /* shape / alignment precondition violated (message names it) */
+  LL_ERR_LAUNCH = -2,        /* hipLaunchKernel failed */
+  LL_ERR_UNSUPPORTED = -3
+};
+
+/* GEMM epilogues (ll_gemm_bf16). */
+enum ll_epilogue {
+  LL_EPI_BIAS = 0,           /* out = bf16(acc + bias)                                         nn.Linear */
+  LL_EPI_BIAS_GELU = 1,      /* out = bf16(gelu_tanh(bf16(acc + bias)))                        ffn.0 + GELU */
+  LL_EPI_BIAS_GATE_RES = 2,  /* out = res + bf16(bf16(acc+bias) * gate[frame(row)])            causal_model.py:456,467 */
+  LL_EPI_BIAS_RES = 3        /* out = res + bf16(acc + bias)                                   causal_model.py:460 */
+};
+
+int ll_version(void);
+const char* ll_last_error(void);
+
+/* ---- norms / modulation ------------------------------------------------------------------------------------- */
+
+/* out[r,:] = LN(x[r,:]) * (1 + s) + t  with s = bf16(mod[scale_idx,:] + e[b,f,scale_idx,:]), t likewise, f = frame of
+ * row r.  Replaces `norm1(x).unflatten(..) * (1 + e[1]) + e[0]` (wan/modules/causal_model.py:445,463-464) and
+ * CausalHead's 2-way form (:506-507).  x,out [B, L, C]; e [B, F, nmod, C]; mod [nmod, C]; L = F * frame_len. */
+int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf16* mod, int nmod, int shift_idx,
+                   int scale_idx, int B, int L, int C, int F, float eps, ll_stream stream);
+
+/* out = LayerNorm(x) * w + b  (norm3, wan/modules/causal_model.py:397-399,460; wan/modules/model.py:89-99). */
+int ll_layernorm_affine(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int rows, int C,
+                        float eps, ll_stream stream);
+
+/* out = bf16(x * rsqrt(mean(x^2) + eps)) * w over the FULL width C (WanRMSNorm, wan/modules/model.py:70-86).
+ * ldx / ldo = row strides in elements (lets the caller normalise a column slice of a fused projection). */
+int ll_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, int ldx, int ldo, float eps,
+               ll_stream stream);
+
+/* Fused q/k RMSNorm + 3-axis RoPE + KV-cache insert for self-attention
+ * (wan/modules/causal_model.py:122-126,206-211,264-269,302-311; causal_rope_apply :32-60).
+ *   qkv      [B, L, 3C]  fused projection output (q | k | v)
+ *   q_out    [B, L, C]   roped queries
+ *   cache_k/v[B, S, C]   rows [write_start, write_start+write_len) receive roped k / v of tokens
+ *                        [roped_offset, roped_offset+write_len)
+ *   rope_f   [1024, nf, 2] (cos,sin) fp32 for the frame axis, rope_hw [frame_len, nhw, 2] for the (h,w) axes;
+ *            nf + nhw = head_dim / 2.  start_frame = current_start / frame_len. */
+int ll_qk_norm_rope_kv_store(const ll_bf16* qkv, const ll_bf16* wq, const ll_bf16* wk, const float* rope_f,
+                             const float* rope_hw, ll_bf16* q_out, ll_bf16* cache_k, ll_bf16* cache_v, int B, int L,
+                             int C, int head_dim, int frame_len, int start_frame, int S, int write_start,
+                             int roped_offset, int write_len, float eps, ll_stream stream);
+
+/* cache[:, dst:dst+n] = cache[:, src:src+n] for K and V, src > dst (left shift that discards evicted tokens while
+ * the sink stays put: wan/modules/causal_model.py:257-260, 874-877).  Overlap-safe (chunked by src-dst). */
+int ll_kv_roll(ll_bf16* cache_k, ll_bf16* cache_v, int B, int S, int C, int dst, int src, int n, ll_stream stream);
+
+/* ---- dense contractions (MFMA) -------------------------------------------------------------------------------- */
+
+/* out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias[N]); bf16 in/out, fp32 accumulate.  K % 64 == 0, N % 8 == 0.
+ * Replaces nn.Linear q/k/v/o, ffn.0/ffn.2, text_embedding, patch_embedding (as GEMM), head.head
+ * (wan/modules/causal_model.py:90-93,406-408,599-603; wan/modules/model.py:172-193).
+ * res [M, ldo] may alias out.  For LL_EPI_BIAS_GATE_RES: gate = bf16(mod[gate_idx,:] + e[b, f, gate_idx, :]) with
+ * b = row / rows_per_batch, f = (row % rows_per_batch) / frame_len; e [B, F, nmod, N], mod [nmod, N]. */
+int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
+                 int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod, int nmod,
+                 int gate_idx, int rows_per_batch, int frame_len, ll_stream stream);
+
+/* Small-M linear (M <= 8): out = act_out(act_in(x) @ w^T + b); act: 0 none, 1 SiLU.  time_embedding /
+ * time_projection (wan/modules/causal_model.py:605-608,976-979). */
+int ll_linear_small(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K,
+                    int act_in, int act_out, ll_stream stream);
+
+/* Non-causal softmax(q k^T / sqrt(d)) v, head_dim 128, keys taken from up to two row ranges of the K/V buffers
+ * ([seg0_start, +seg0_len) then [seg1_start, +seg1_len)): frame sink + sliding window of the KV cache, or the 512
+ * text tokens for cross-attention.  Replaces attention()/flash_attention() (wan/modules/attention.py:43-197) and the
+ * sink/window gather + cat (wan/modules/causal_model.py:331-360).
+ *   q,out [B, Lq, H*128] with row strides ldq/ldo; k,v [B, Sk, H*128] with row stride ldk, batch stride Sk*ldk. */
+int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H, int ldq,
+                  int ldo, int ldk, long long k_batch_stride, int seg0_start, int seg0_len, int seg1_start,
+                  int seg1_len, float scale, ll_stream stream);
+
+/* ---- embeddings / head / scheduler ------------------------------------------------------------------------------ */
+
+/* im2col of Conv3d k=s=(1,2,2) (wan/modules/causal_model.py:599-600,959-963): x [B,F,Cin,H,W] (the wrapper's layout,
+ * utils/wan_wrapper.py:249 permute folded in) -> patches [B, F*(H/2)*(W/2), Cin*4] with column (c, p, q). */
+int ll_patchify(const ll_bf16* x, ll_bf16* patches, int B, int F, int Cin, int H, int W, ll_stream stream);
+
+/* sinusoidal_embedding_1d (wan/modules/model.py:15-25) in fp64 then cast to bf16: out [n, dim]. */
+int ll_sinusoid(const float* t, ll_bf16* out, int n, int dim, ll_stream stream);
+
+/* unpatchify ('fhwpqrc->cfphqwr', wan/modules/causal_model.py:1240-1263) + flow->x0 in fp64
+ * (utils/wan_wrapper.py:175-199): head [B, F*h*w, 4*Cout] -> flow, x0 [B,F,Cout,H,W]; x0 = xt - sigma[b,f]*flow. */
+int ll_unpatchify_x0(const ll_bf16* head, const ll_bf16* xt, const float* sigma, ll_bf16* flow, ll_bf16* x0, int B,
+                     int F, int Cout, int H, int W, ll_stream stream);
+
+/* FlowMatchScheduler.add_noise (utils/scheduler.py:159-176): out = bf16((1-sigma)*x0 + sigma*noise), fp32,
+ * sigma[n] per leading index; x0/noise/out [N, inner]. */
+int ll_add_noise(const ll_bf16* x0, const ll_bf16* noise, const float* sigma, ll_bf16* out, int N, long long inner,
+                 ll_stream stream);
+
+/* out[i] = sigmas[argmin_j |timesteps[j] - t[i]|]: the table lookup shared by flow->x0 and add_noise
+ * (utils/wan_wrapper.py:195-197; utils/scheduler.py:172-174).  All fp32 device arrays; lowest index wins ties. */
+int ll_sigma_lookup(const float* t, const float* timesteps, const float* sigmas, float* out, int n, int n_table,
+                    ll_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LONGLIVE_HIP_H */

@@ -1,0 +1,64 @@
+"""ctypes binding of liblonglive_hip.so (the C ABI declared in include/longlive_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is absent, import of the ops
+fails loudly (RuntimeError) rather than silently running something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblonglive_hip.so")
+
+_p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/longlive_hip.h 1:1
+SIGNATURES = {
+    "ll_version": [],
+    "ll_last_error": [],
+    "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "ll_rmsnorm": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ll_qk_norm_rope_kv_store": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "ll_kv_roll": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ll_gemm_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ll_linear_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p],
+    "ll_patchify": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "ll_sinusoid": [_p, _p, _i, _i, _p],
+    "ll_unpatchify_x0": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ll_add_noise": [_p, _p, _p, _p, _i, _ll, _p],
+    "ll_sigma_lookup": [_p, _p, _p, _p, _i, _i, _p],
+}
+_RESTYPES = {"ll_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library (once).  Raises RuntimeError if it is missing: build it with
+    `python -c 'import __graft_entry__ as g; g.build()'` or `make -C longlive_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built (make -C longlive_amd/csrc). "
+            "longlive_amd has no CPU fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:  # pragma: no cover
+            raise RuntimeError(f"{LIB_PATH} does not export {name}") from exc
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ll_last_error()
+        raise RuntimeError(f"longlive_hip {what} failed (status {rc}): {msg.decode() if msg else ''}")

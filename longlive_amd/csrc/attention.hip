@@ -1,0 +1,252 @@
+// Flash attention forward for head_dim 128 on gfx950: frame-sink + sliding-window self-attention straight out of the
+// KV cache (no gather/cat), and cross-attention over the 512 text tokens.  Non-causal, no mask: every query of the
+// block sees [seg0 | seg1] (wan/modules/causal_model.py:331-360).
+//
+// Structure (per workgroup: NW waves x 32 query rows of one head; per wave the whole 32 x 128 Q slab in registers):
+//   S^T = K . Q^T      "swapped" product (A := K tile from LDS, B := Q^T in registers, v_mfma_f32_32x32x16_bf16): a lane
+//                       then holds 32 scores of ONE query (its MFMA column), so the softmax row reductions are 31 in-lane
+//                       max/adds + one lane^32 wave shuffle; no LDS round trip, no P buffer
+//   P  = exp2(c.S^T - c.m) in registers -> bf16; the 32x32 f32 accumulator tile IS the B operand of the next MFMA
+//                       (k = key index permuted as 16s + 8(j>>2) + 4h + (j&3))
+//   O^T += V^T . P^T    A := V^T fetched from the row-major V tile in LDS with ds_read_b64_tr_b16 (hardware transpose) in
+//                       that same permuted key order; O^T accumulators (128 d x 32 q = 64 f32/lane) hold one query per lane
+//                       so the online-softmax rescale is a per-lane scalar
+//   K/V tiles (64 keys x 128 d, 16 KiB each) : coalesced 16-B global loads -> registers (issued before the tile's MFMAs so
+//                       HBM latency hides under compute) -> XOR-swizzled LDS (double buffered, one barrier per tile).
+//   LDS swizzles: K row = 256 B; 16-B chunk c of key r at position c ^ (r & 15)  -> ds_read_b128 A-fragments conflict-free
+//                 V row = 256 B; 16-B chunk c of key r at position c ^ ((r & 3) << 2) -> tr_b16 reads conflict-free
+#include "common.h"
+
+#define KT 64                       // keys per tile
+#define TILE_B (KT * 128 * 2)       // 16 KiB
+
+template <int NW>
+struct AttnStage {                  // per-thread staging registers for one K + one V tile
+  static constexpr int NCHUNK = 1024 / (NW * 64);
+  uint4 k[NCHUNK], v[NCHUNK];
+};
+
+struct Segs {
+  int s0, n0, s1, n1, nt0, nt;      // two key ranges and their tile counts
+};
+
+__device__ __forceinline__ void tile_range(const Segs& sg, int t, int& base, int& valid) {
+  if (t < sg.nt0) {
+    base = sg.s0 + t * KT;
+    valid = sg.n0 - t * KT;
+  } else {
+    int u = t - sg.nt0;
+    base = sg.s1 + u * KT;
+    valid = sg.n1 - u * KT;
+  }
+  valid = valid < KT ? valid : KT;
+}
+
+template <int NW>
+__device__ __forceinline__ void load_tile(AttnStage<NW>& st, const bf16* __restrict__ kh, const bf16* __restrict__ vh,
+                                          int ldk, int base, int valid, int tid) {
+#pragma unroll
+  for (int i = 0; i < AttnStage<NW>::NCHUNK; ++i) {
+    int cid = tid + i * NW * 64;
+    int key = cid >> 4, ch = cid & 15;
+    int row = base + (key < valid ? key : valid - 1);  // clamp: masked keys re-read the last valid row
+    size_t off = (size_t)row * ldk + ch * 8;
+    st.k[i] = *reinterpret_cast<const uint4*>(kh + off);
+    st.v[i] = *reinterpret_cast<const uint4*>(vh + off);
+  }
+}
+
+template <int NW>
+__device__ __forceinline__ void store_tile(const AttnStage<NW>& st, char* kl, char* vl, int tid) {
+#pragma unroll
+  for (int i = 0; i < AttnStage<NW>::NCHUNK; ++i) {
+    int cid = tid + i * NW * 64;
+    int key = cid >> 4, ch = cid & 15;
+    *reinterpret_cast<uint4*>(kl + key * 256 + ((ch ^ (key & 15)) << 4)) = st.k[i];
+    *reinterpret_cast<uint4*>(vl + key * 256 + ((ch ^ ((key & 3) << 2)) << 4)) = st.v[i];
+  }
+}
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
+                                                                const bf16* __restrict__ Vc, bf16* __restrict__ O,
+                                                                int Lq, int ldq, int ldo, int ldk,
+                                                                long long k_batch_stride, Segs sg, float c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | V tile] = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+
+  const bf16* kh = Kc + (size_t)b * k_batch_stride + head * 128;
+  const bf16* vh = Vc + (size_t)b * k_batch_stride + head * 128;
+
+  // Q^T fragments: lane (r, h) holds Q[q0 + r][16 ks + 8 h .. +7] for ks = 0..7  (B operand of S^T = K Q^T)
+  bf16x8 qf[8];
+  {
+    int qr = q0 + r;
+    qr = qr < Lq ? qr : Lq - 1;
+    const bf16* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 128 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  AttnStage<NW> st;
+  int base, valid;
+  tile_range(sg, 0, base, valid);
+  load_tile<NW>(st, kh, vh, ldk, base, valid, tid);
+  store_tile<NW>(st, smem, smem + TILE_B, tid);
+  __syncthreads();
+
+  // per-lane LDS offsets
+  // K A-fragment: key = 32 kb + r, chunk = 2 ks + h  ->  off = key*256 + ((chunk ^ (key & 15)) << 4)
+  // V tr-read   : lane = 16 g + 4 q + p; key = K0 + q (K0 = 32 kb + 16 s2 + 4 h [+8]); d0 = 32 db + 16 (g & 1) + 4 p
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+
+  for (int t = 0; t < sg.nt; ++t) {
+    const char* kl = smem + (t & 1) * 2 * TILE_B;
+    const char* vl = kl + TILE_B;
+    int cur_valid = valid;
+    const bool more = (t + 1 < sg.nt);
+    if (more) {
+      tile_range(sg, t + 1, base, valid);
+      load_tile<NW>(st, kh, vh, ldk, base, valid, tid);  // global -> regs, consumed after this tile's MFMAs
+    }
+
+    // ---- S^T = K Q^T : 2 key blocks x 8 k-steps ------------------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        int key = 32 * kb + r;
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kl + key * 256 + (((2 * ks + h) ^ (key & 15)) << 4));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    // lane now holds, for query r: s[kb][i] = score of key 32 kb + (i & 3) + 8 (i >> 2) + 4 h
+    if (cur_valid < KT) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= cur_valid) s[kb][i] = -INFINITY;
+        }
+    }
+
+    // ---- online softmax (base-2, scale folded: p = exp2(c s - c m)) ------------------------------------------
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float m_new = fmaxf(m_run, mx);
+    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    float mc = m_new * c;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c, -mc));
+        s[kb][i] = p;
+        rs += p;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+
+    // P^T fragments (B operand): k-step (kb, s2) uses accumulator registers 8 s2 .. 8 s2 + 7 of s[kb]
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kb][s2][j] = (bf16)s[kb][8 * s2 + j];
+
+    // ---- O^T += V^T P^T : 4 d-blocks x 4 k-steps -----------------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        int key0 = 32 * kb + 16 * s2 + 4 * h + tq;   // row of the first 4-key block this lane addresses
+        int key1 = key0 + 8;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          int dbyte = (32 * db + 16 * tg1 + 4 * tp) * 2;     // byte offset of d0 inside the 256-B row
+          int ch = dbyte >> 4, sub = dbyte & 15;
+          int a0 = key0 * 256 + ((ch ^ ((key0 & 3) << 2)) << 4) + sub;
+          int a1 = key1 * 256 + ((ch ^ ((key1 & 3) << 2)) << 4) + sub;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vl + a0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vl + a1));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], o[db], 0, 0, 0);
+        }
+      }
+    }
+
+    if (more) {
+      char* nk = smem + ((t + 1) & 1) * 2 * TILE_B;
+      store_tile<NW>(st, nk, nk + TILE_B, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O^T[d][q] / l  ->  out[q][head*128 + d]; lane holds d = 32 db + 8 g4 + 4 h + (0..3) --------------
+  int qr = q0 + r;
+  if (qr < Lq) {
+    float inv = 1.0f / l_run;
+    bf16* op = O + ((size_t)b * Lq + qr) * ldo + head * 128 + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (bf16)(o[db][4 * g4 + j] * inv);
+        *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * g4) = w;
+      }
+  }
+}
+
+extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H,
+                             int ldq, int ldo, int ldk, long long k_batch_stride, int seg0_start, int seg0_len,
+                             int seg1_start, int seg1_len, float scale, ll_stream stream) {
+  LL_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && ldk % 8 == 0, "ll_flash_attn: row strides must be multiples of 8 elements");
+  LL_REQUIRE(ldq >= H * 128 && ldo >= H * 128 && ldk >= H * 128, "ll_flash_attn: row stride smaller than H*128");
+  LL_REQUIRE(seg0_len > 0 && seg1_len >= 0 && seg0_start >= 0 && seg1_start >= 0, "ll_flash_attn: needs a non-empty first key range");
+  if (B == 0 || Lq == 0 || H == 0) return LL_OK;
+  Segs sg;
+  sg.s0 = seg0_start; sg.n0 = seg0_len; sg.s1 = seg1_start; sg.n1 = seg1_len;
+  if (sg.n1 > 0 && sg.s1 == sg.s0 + sg.n0) { sg.n0 += sg.n1; sg.n1 = 0; }   // contiguous: one range
+  sg.nt0 = (sg.n0 + KT - 1) / KT;
+  sg.nt = sg.nt0 + (sg.n1 + KT - 1) / KT;
+  float c = scale * 1.4426950408889634f;
+  constexpr int NW = 4;
+  dim3 grid((Lq + NW * 32 - 1) / (NW * 32), H, B), block(NW * 64);
+  hipLaunchKernelGGL(flash_attn_kernel<NW>, grid, block, 4 * TILE_B, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
+                     (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, sg, c);
+  return ll_check_launch("ll_flash_attn");
+}

@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA bf16, LDS 160 KiB/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/longlive_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LL_WAVE 64
+
+// bf16 <-> f32.  (bf16)f lowers to v_cvt_pk_bf16_f32 on gfx950: round-to-nearest-even, NaN stays NaN.
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float f) { return (bf16)f; }
+// round an fp32 value to bf16 precision and come back (the reference's intermediate rounding points)
+__device__ __forceinline__ float rbf(float f) { return (float)((bf16)f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// gelu(tanh approx) as x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3); identical to 0.5x(1+tanh u).
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  // exp(-2u) via exp2; saturates cleanly: u -> +inf gives x, u -> -inf gives 0 * x -> -0/0 guarded by rcp(inf)=0
+  float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ float silu(float x) {
+  float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// host-side error plumbing (api.hip)
+void ll_set_error(const char* fmt, ...);
+#define LL_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ll_set_error(__VA_ARGS__);         \
+      return LL_ERR_INVALID_ARG;         \
+    }                                    \
+  } while (0)
+
+int ll_check_launch(const char* what);

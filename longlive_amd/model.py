@@ -1,0 +1,300 @@
+"""CausalWanModel on MI355X: the 30-block causal video DiT forward with KV cache, run entirely through
+liblonglive_hip.so (hand-written gfx950 kernels).  Host-side mirror of
+wan/modules/causal_model.py::CausalWanModel._forward_inference (:907-1068).
+
+The module tree exists only to carry parameters under the reference's state-dict names
+(`blocks.{i}.self_attn.q.weight`, `blocks.{i}.ffn.0.weight`, `head.head.weight`, ... causal_model.py:90-95,
+395-411,491-495,599-619) so that reference checkpoints load with `load_state_dict`; no nn.Module.forward of a
+child is ever called.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kv_cache import KVPlan, plan_update
+from .synth import WanConfig
+
+bf16 = torch.bfloat16
+
+
+class _Lin(nn.Module):
+    def __init__(self, out_f: int, in_f: int, device, dtype):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(out_f, in_f, device=device, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(out_f, device=device, dtype=dtype), requires_grad=False)
+
+
+class _Norm(nn.Module):
+    def __init__(self, dim: int, device, dtype, bias: bool = False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(dim, device=device, dtype=dtype), requires_grad=False)
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, device, dtype):
+        super().__init__()
+        self.q, self.k, self.v, self.o = (_Lin(dim, dim, device, dtype) for _ in range(4))
+        self.norm_q, self.norm_k = _Norm(dim, device, dtype), _Norm(dim, device, dtype)
+        # read by the reference pipeline's _set_all_modules_max_attention_size (causal_inference.py:319-329)
+        self.max_attention_size = 32760
+
+
+class _Block(nn.Module):
+    def __init__(self, cfg: WanConfig, device, dtype):
+        super().__init__()
+        d = cfg.dim
+        self.self_attn = _Attn(d, device, dtype)
+        self.cross_attn = _Attn(d, device, dtype)
+        del self.cross_attn.max_attention_size
+        self.norm3 = _Norm(d, device, dtype, bias=True)
+        self.ffn = nn.ModuleList([_Lin(cfg.ffn_dim, d, device, dtype), nn.Identity(), _Lin(d, cfg.ffn_dim, device, dtype)])
+        self.modulation = nn.Parameter(torch.zeros(1, 6, d, device=device, dtype=dtype), requires_grad=False)
+
+
+class _Head(nn.Module):
+    def __init__(self, cfg: WanConfig, device, dtype):
+        super().__init__()
+        self.head = _Lin(math.prod(cfg.patch_size) * cfg.out_dim, cfg.dim, device, dtype)
+        self.modulation = nn.Parameter(torch.zeros(1, 2, cfg.dim, device=device, dtype=dtype), requires_grad=False)
+
+
+class _Conv(nn.Module):
+    def __init__(self, cfg: WanConfig, device, dtype):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cfg.dim, cfg.in_dim, *cfg.patch_size, device=device, dtype=dtype),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cfg.dim, device=device, dtype=dtype), requires_grad=False)
+
+
+def _kv_state(cache: dict) -> Tuple[int, int]:
+    """(global_end_index, local_end_index) as python ints.  Accepts the reference's cache dicts
+    (int64[1] device tensors, pipeline/causal_inference.py:275-276): they are read back ONCE and shadowed under
+    `_ll_idx`; afterwards the shadow is authoritative and the tensors are only written (async fill_)."""
+    st = cache.get("_ll_idx")
+    if st is None:
+        g, e = cache["global_end_index"], cache["local_end_index"]
+        st = [int(g.item()) if torch.is_tensor(g) else int(g), int(e.item()) if torch.is_tensor(e) else int(e)]
+        cache["_ll_idx"] = st
+    return st[0], st[1]
+
+
+def _kv_commit(cache: dict, G: int, E: int) -> None:
+    cache["_ll_idx"] = [G, E]
+    for key, val in (("global_end_index", G), ("local_end_index", E)):
+        cur = cache.get(key)
+        if torch.is_tensor(cur):
+            cur.fill_(val)
+        else:
+            cache[key] = val
+
+
+class CausalWanModelHIP(nn.Module):
+    """Drop-in for the KV-cache inference branch of CausalWanModel."""
+
+    def __init__(self, cfg: WanConfig, device="cuda", dtype=bf16):
+        super().__init__()
+        assert dtype == bf16, "the HIP path computes in bf16 (inference.py:134)"
+        assert cfg.head_dim == 128, "kernels are specialised for head_dim 128 (Wan2.1-T2V-1.3B: 1536 / 12)"
+        assert cfg.patch_size == (1, 2, 2)
+        self.cfg = cfg
+        d = cfg.dim
+        self.patch_embedding = _Conv(cfg, device, dtype)
+        self.text_embedding = nn.ModuleList([_Lin(d, cfg.text_dim, device, dtype), nn.Identity(), _Lin(d, d, device, dtype)])
+        self.time_embedding = nn.ModuleList([_Lin(d, cfg.freq_dim, device, dtype), nn.Identity(), _Lin(d, d, device, dtype)])
+        self.time_projection = nn.ModuleList([nn.Identity(), _Lin(6 * d, d, device, dtype)])
+        self.blocks = nn.ModuleList([_Block(cfg, device, dtype) for _ in range(cfg.num_layers)])
+        self.head = _Head(cfg, device, dtype)
+        # attributes the reference pipelines read / write (causal_inference.py:54,135,310-329;
+        # interactive_causal_inference.py:73-84)
+        self.local_attn_size = cfg.local_attn_size
+        self.sink_size = cfg.sink_size
+        self.max_attention_size = 32760 if cfg.local_attn_size == -1 else cfg.local_attn_size * 1560
+        for b in self.blocks:
+            b.self_attn.max_attention_size = self.max_attention_size
+        self.num_frame_per_block = 1
+        self.block_mask = None
+        self._packed = None
+        self._rope_f = None
+        self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._ctx_cache = None
+
+    # ---- parameter packing -------------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._rope_f = None
+        self._rope_hw = {}
+        self._ctx_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._packed = None
+        self._ctx_cache = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    @staticmethod
+    def _prepare_blockwise_causal_attn_mask(*args, **kwargs):
+        """The reference builds a flex-attention mask before recaching (interactive_causal_inference.py:73-84), but
+        the KV-cache branch of self-attention never reads it (causal_model.py:205-360).  Kept for call compatibility."""
+        return None
+
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        P = []
+        for blk in self.blocks:
+            sa, ca = blk.self_attn, blk.cross_attn
+            P.append(dict(
+                wqkv=torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous(),
+                bqkv=torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous(),
+                mod=blk.modulation.detach().reshape(6, -1).contiguous(),
+            ))
+        self._packed = P
+        return P
+
+    def _rope_tables(self, hp: int, wp: int, device):
+        """fp32 (cos, sin) tables from the reference's fp64 angles (model.py:29-36; causal_model.py:622-629):
+        rope_f [1024, nf, 2] for the frame axis, rope_hw [hp*wp, 2*c3, 2] = (h angles | w angles) per spatial token."""
+        d = self.cfg.head_dim
+        half = d // 2
+        c3 = half // 3
+        nf = half - 2 * c3
+
+        def angles(n, dim):
+            return torch.outer(torch.arange(n, dtype=torch.float64),
+                               1.0 / torch.pow(10000.0, torch.arange(0, dim, 2, dtype=torch.float64).div(dim)))
+
+        if self._rope_f is None:
+            a = angles(1024, d - 4 * (d // 6))
+            assert a.shape[1] == nf
+            self._rope_f = torch.stack([a.cos(), a.sin()], -1).float().contiguous().to(device)
+        key = (hp, wp)
+        if key not in self._rope_hw:
+            ah = angles(1024, 2 * (d // 6))[:hp]          # [hp, c3]
+            aw = angles(1024, 2 * (d // 6))[:wp]          # [wp, c3]
+            a = torch.cat([ah.view(hp, 1, c3).expand(hp, wp, c3), aw.view(1, wp, c3).expand(hp, wp, c3)], -1)
+            a = a.reshape(hp * wp, 2 * c3)
+            self._rope_hw[key] = torch.stack([a.cos(), a.sin()], -1).float().contiguous().to(device)
+        return self._rope_f, self._rope_hw[key]
+
+    # ---- embeddings ---------------------------------------------------------------------------------------------
+    def time_embed(self, t: torch.Tensor):
+        """t [B,F] -> e [B*F, C], e0 [B,F,6,C]   (causal_model.py:976-979)."""
+        c = self.cfg
+        tf = t.reshape(-1).to(torch.float32).contiguous()
+        emb = ops.sinusoid(tf, c.freq_dim)
+        h = ops.linear_small(emb, self.time_embedding[0].weight, self.time_embedding[0].bias, act_out=1)
+        e = ops.linear_small(h, self.time_embedding[2].weight, self.time_embedding[2].bias)
+        e0 = ops.linear_small(e, self.time_projection[1].weight, self.time_projection[1].bias, act_in=1)
+        return e, e0.view(*t.shape, 6, c.dim)
+
+    def text_embed(self, context: torch.Tensor):
+        """[B, text_len, text_dim] -> [B, text_len, C]   (causal_model.py:984-989).  The reference recomputes this
+        every forward; its only consumer is the cross-attention K/V projection, which is cached per prompt
+        (model.py:174-183), so it is evaluated lazily and memoised on the prompt tensor."""
+        key = (context.data_ptr(), context._version)
+        if self._ctx_cache is not None and self._ctx_cache[:2] == key:
+            return self._ctx_cache[2]
+        c = self.cfg
+        ctx = context.to(bf16)
+        if ctx.shape[1] < c.text_len:
+            ctx = torch.cat([ctx, ctx.new_zeros(ctx.shape[0], c.text_len - ctx.shape[1], ctx.shape[2])], 1)
+        ctx = ctx.contiguous()
+        h = ops.gemm(ctx, self.text_embedding[0].weight, self.text_embedding[0].bias, ops.EPI_BIAS_GELU)
+        out = ops.gemm(h, self.text_embedding[2].weight, self.text_embedding[2].bias)
+        self._ctx_cache = (key[0], key[1], out, context)   # holding `context` keeps its address from being reused
+        return out
+
+    # ---- forward -----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_frames(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, kv_cache: List[dict],
+                       crossattn_cache: List[dict], current_start: int = 0,
+                       sink_recache_after_switch: bool = False, sigma: Optional[torch.Tensor] = None):
+        """x [B,F,Cin,H,W] (the wrapper's layout); t [B,F]; context [B,text_len,text_dim].
+        Returns the head output [B, L, 4*Cout] (pre-unpatchify), or (flow, x0) in [B,F,C,H,W] when `sigma`
+        (float32 [B*F]) is given."""
+        c = self.cfg
+        B, F, Cin, H, W = x.shape
+        hp, wp = H // 2, W // 2
+        fs = hp * wp
+        L = F * fs
+        Hh, D, C = c.num_heads, c.head_dim, c.dim
+        assert current_start % fs == 0, "current_start must sit on a frame boundary"
+        x = x.to(bf16).contiguous()
+        P = self._pack()
+        rope_f, rope_hw = self._rope_tables(hp, wp, x.device)
+
+        pe = self.patch_embedding
+        xs = ops.gemm(ops.patchify(x), pe.weight.view(C, -1), pe.bias)                      # [B, L, C]
+        e, e0 = self.time_embed(t)
+        need_ctx = any(not cc["is_init"] for cc in crossattn_cache)
+        ctx = self.text_embed(context) if need_ctx else None
+
+        q_buf = torch.empty(B, L, Hh, D, dtype=bf16, device=x.device)
+        plans: List[KVPlan] = []
+        for i, blk in enumerate(self.blocks):
+            pk, kvc, cac = P[i], kv_cache[i], crossattn_cache[i]
+            sa, ca = blk.self_attn, blk.cross_attn
+            # --- self attention (causal_model.py:444-456) ---
+            h1 = ops.ln_modulate(xs, e0, pk["mod"], 0, 1, F, c.eps)
+            qkv = ops.gemm(h1, pk["wqkv"], pk["bqkv"])
+            G, E = _kv_state(kvc)
+            S = kvc["k"].shape[1]
+            plan = plan_update(current_start, L, G, E, S, self.sink_size * fs, self.local_attn_size,
+                               sa.max_attention_size, sink_recache_after_switch)
+            plans.append(plan)
+            if plan.roll is not None:
+                ops.kv_roll(kvc["k"], kvc["v"], *plan.roll)
+            ops.qk_norm_rope_kv_store(qkv, sa.norm_q.weight, sa.norm_k.weight, rope_f, rope_hw, q_buf.view(B, L, C),
+                                      kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
+                                      plan.roped_offset, plan.write_len, c.eps)
+            att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments)
+            ops.gemm(att.view(B, L, C), sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
+                     mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
+            # --- cross attention (causal_model.py:460; model.py:159-194) ---
+            xn = ops.layernorm_affine(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
+            qc = ops.rmsnorm(ops.gemm(xn, ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
+            if not cac["is_init"]:
+                kc = ops.gemm(ctx, ca.k.weight, ca.k.bias)
+                if cac["k"].shape != (B, c.text_len, Hh, D) or not cac["k"].is_contiguous():
+                    cac["k"] = torch.empty(B, c.text_len, Hh, D, dtype=bf16, device=x.device)
+                    cac["v"] = torch.empty(B, c.text_len, Hh, D, dtype=bf16, device=x.device)
+                ops.rmsnorm(kc, ca.norm_k.weight, c.eps, out=cac["k"].view(B, c.text_len, C))
+                ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
+                cac["is_init"] = True
+            atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)])
+            ops.gemm(atc.view(B, L, C), ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
+            # --- FFN (causal_model.py:462-468) ---
+            h2 = ops.ln_modulate(xs, e0, pk["mod"], 3, 4, F, c.eps)
+            ff = ops.gemm(h2, blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
+            ops.gemm(ff, blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
+                     mod=pk["mod"], gate_idx=5, rows_per_batch=L, frame_len=fs)
+        # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
+        for kvc, plan in zip(kv_cache, plans):
+            _kv_commit(kvc, plan.G_new, plan.E_new)
+        # --- head (causal_model.py:497-508,1065) ---
+        eh = e.view(B, F, 1, C).expand(B, F, 2, C).contiguous()
+        hd = ops.ln_modulate(xs, eh, self.head.modulation.view(2, C), 0, 1, F, c.eps)
+        ho = ops.gemm(hd, self.head.head.weight, self.head.head.bias)                       # [B, L, 4*Cout]
+        if sigma is None:
+            return ho
+        return ops.unpatchify_x0(ho, x, sigma)
+
+    def forward(self, x, t=None, context=None, seq_len=None, kv_cache=None, crossattn_cache=None,
+                current_start: int = 0, cache_start=None, sink_recache_after_switch: bool = False, **unused):
+        """Reference-compatible call (causal_model.py:1230-1238): x [B,C,F,H,W] -> flow [B,C,F,H,W]."""
+        if kv_cache is None:
+            raise NotImplementedError("only the KV-cache inference branch exists (the reference's training branch "
+                                      "is itself a stub: causal_model.py:1102-1103)")
+        xf = x.permute(0, 2, 1, 3, 4).contiguous()
+        B, F = xf.shape[:2]
+        zero = torch.zeros(B * F, dtype=torch.float32, device=xf.device)
+        flow, _ = self.forward_frames(xf, t, context, kv_cache, crossattn_cache, current_start,
+                                      sink_recache_after_switch, sigma=zero)
+        return flow.permute(0, 2, 1, 3, 4)

@@ -1,0 +1,239 @@
+"""Tensor-level wrappers over the C ABI.  torch is plumbing here (device memory + the current HIP stream);
+all arithmetic happens in liblonglive_hip.so.  Every wrapper checks operand shapes on the host before a launch:
+a kernel that faults can take the whole 8-GPU host down.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+bf16 = torch.bfloat16
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_GATE_RES, EPI_BIAS_RES = 0, 1, 2, 3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=bf16) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a device tensor (longlive_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor, got strides {t.stride()}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float, out=None):
+    """x [B,L,C]; e [B,F,nmod,C]; mod [nmod,C] (causal_model.py:445,463-464,506-507)."""
+    _chk(x, "x"); _chk(e, "e"); _chk(mod, "mod")
+    B, L, Cc = x.shape
+    nmod = mod.shape[-2]
+    assert e.shape == (B, num_frames, nmod, Cc), (e.shape, (B, num_frames, nmod, Cc))
+    assert mod.numel() == nmod * Cc
+    out = torch.empty_like(x) if out is None else _chk(out, "out")
+    assert out.shape == x.shape
+    lib = _lib.load()
+    _lib.check(lib.ll_ln_modulate(x.data_ptr(), out.data_ptr(), e.data_ptr(), mod.data_ptr(), nmod, shift_idx,
+                                  scale_idx, B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate")
+    return out
+
+
+def layernorm_affine(x, w, b, eps: float, out=None):
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
+    Cc = x.shape[-1]
+    assert w.numel() == Cc and b.numel() == Cc
+    out = torch.empty_like(x) if out is None else _chk(out, "out")
+    assert out.shape == x.shape
+    lib = _lib.load()
+    _lib.check(lib.ll_layernorm_affine(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), x.numel() // Cc, Cc,
+                                       eps, _stream()), "ll_layernorm_affine")
+    return out
+
+
+def rmsnorm(x, w, eps: float, out=None, C: Optional[int] = None):
+    """RMSNorm over the first C columns of each row of a 2-D (or flattened) row-major view.  x may be a column
+    slice of a wider buffer as long as its last-dim stride is 1 and rows are evenly strided."""
+    assert x.dtype == bf16 and x.is_cuda and x.stride(-1) == 1
+    Cc = x.shape[-1] if C is None else C
+    x2 = x.flatten(0, -2) if x.dim() > 2 else x
+    assert x2.dim() == 2 and x2.data_ptr() == x.data_ptr(), "rows of x must be evenly strided"
+    rows, ldx = x2.shape[0], x2.stride(0)
+    _chk(w, "w")
+    assert w.numel() == Cc
+    if out is None:
+        out = torch.empty(rows, Cc, dtype=bf16, device=x.device)
+    assert out.dtype == bf16 and out.is_cuda and out.stride(-1) == 1
+    o2 = out.flatten(0, -2) if out.dim() > 2 else out
+    assert o2.dim() == 2 and o2.data_ptr() == out.data_ptr() and o2.shape[0] == rows and o2.shape[1] >= Cc
+    lib = _lib.load()
+    _lib.check(lib.ll_rmsnorm(x2.data_ptr(), w.data_ptr(), o2.data_ptr(), rows, Cc, ldx, o2.stride(0), eps, _stream()),
+               "ll_rmsnorm")
+    return out
+
+
+def qk_norm_rope_kv_store(qkv, wq, wk, rope_f, rope_hw, q_out, cache_k, cache_v, head_dim: int, frame_len: int,
+                          start_frame: int, write_start: int, roped_offset: int, write_len: int, eps: float):
+    """qkv [B,L,3C] -> q_out [B,L,C]; cache_k/v [B,S,H,D] rows [write_start, +write_len) updated in place."""
+    _chk(qkv, "qkv"); _chk(wq, "wq"); _chk(wk, "wk"); _chk(q_out, "q_out"); _chk(cache_k, "cache_k"); _chk(cache_v, "cache_v")
+    _chk(rope_f, "rope_f", torch.float32); _chk(rope_hw, "rope_hw", torch.float32)
+    B, L, C3 = qkv.shape
+    Cc = C3 // 3
+    assert C3 == 3 * Cc and q_out.shape == (B, L, Cc)
+    S = cache_k.shape[1]
+    assert cache_k.shape[0] == B and cache_k.numel() == B * S * Cc and cache_v.shape == cache_k.shape
+    half = head_dim // 2
+    nf = half - 2 * (half // 3)
+    assert rope_f.shape == (1024, nf, 2), rope_f.shape
+    assert rope_hw.shape == (frame_len, half - nf, 2), rope_hw.shape
+    lib = _lib.load()
+    _lib.check(lib.ll_qk_norm_rope_kv_store(qkv.data_ptr(), wq.data_ptr(), wk.data_ptr(), rope_f.data_ptr(),
+                                            rope_hw.data_ptr(), q_out.data_ptr(), cache_k.data_ptr(),
+                                            cache_v.data_ptr(), B, L, Cc, head_dim, frame_len, start_frame, S,
+                                            write_start, roped_offset, write_len, eps, _stream()),
+               "ll_qk_norm_rope_kv_store")
+    return q_out
+
+
+def kv_roll(cache_k, cache_v, dst: int, src: int, n: int):
+    _chk(cache_k, "cache_k"); _chk(cache_v, "cache_v")
+    B, S = cache_k.shape[:2]
+    Cc = cache_k.numel() // (B * S)
+    assert cache_v.shape == cache_k.shape
+    lib = _lib.load()
+    _lib.check(lib.ll_kv_roll(cache_k.data_ptr(), cache_v.data_ptr(), B, S, Cc, dst, src, n, _stream()), "ll_kv_roll")
+
+
+def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
+         rows_per_batch: int = 0, frame_len: int = 0):
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias).  x may be any [..., K] contiguous tensor."""
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape == (N, K) and bias.numel() == N, (w.shape, bias.shape, K)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=bf16, device=x.device)
+    _chk(out, "out")
+    assert out.numel() == M * N
+    nmod = 0
+    if epilogue in (EPI_BIAS_GATE_RES, EPI_BIAS_RES):
+        _chk(res, "res")
+        assert res.numel() == M * N
+    if epilogue == EPI_BIAS_GATE_RES:
+        _chk(e, "e"); _chk(mod, "mod")
+        nmod = mod.shape[-2]
+        assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
+        assert e.numel() == (M // frame_len) * nmod * N, (e.shape, M, frame_len)
+    lib = _lib.load()
+    _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
+                                _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
+               "ll_gemm_bf16")
+    return out
+
+
+def linear_small(x, w, bias, act_in: int = 0, act_out: int = 0):
+    """Few-row linear (time embedding); rows are processed 8 at a time."""
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape == (N, K) and bias.numel() == N
+    out = torch.empty(*x.shape[:-1], N, dtype=bf16, device=x.device)
+    lib = _lib.load()
+    x2, o2 = x.view(M, K), out.view(M, N)
+    for m0 in range(0, M, 8):
+        m = min(8, M - m0)
+        _lib.check(lib.ll_linear_small(x2[m0:].data_ptr(), w.data_ptr(), bias.data_ptr(), o2[m0:].data_ptr(), m, N, K,
+                                       act_in, act_out, _stream()), "ll_linear_small")
+    return out
+
+
+def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None):
+    """q [B,Lq,H,128] (contiguous); k,v [B,Sk,H,128]; keys = concatenation of up to two row ranges
+    [(start, end), ...] of k/v.  Returns [B,Lq,H,128]."""
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
+    B, Lq, H, D = q.shape
+    assert D == 128, "kernel is specialised for head_dim 128"
+    Sk = k.shape[1]
+    assert k.shape == (B, Sk, H, D) and v.shape == k.shape
+    segs = [(int(a), int(b)) for a, b in segments if b > a]
+    assert 1 <= len(segs) <= 2, segments
+    for a, b_ in segs:
+        assert 0 <= a < b_ <= Sk, (segments, Sk)
+    (s0, e0) = segs[0]
+    (s1, e1) = segs[1] if len(segs) == 2 else (0, 0)
+    out = torch.empty_like(q) if out is None else _chk(out, "out")
+    assert out.shape == q.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    lib = _lib.load()
+    _lib.check(lib.ll_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, H, H * D, H * D,
+                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, _stream()), "ll_flash_attn")
+    return out
+
+
+def patchify(x):
+    """x [B,F,Cin,H,W] -> [B, F*(H/2)*(W/2), Cin*4]."""
+    _chk(x, "x")
+    B, F, Cin, H, W = x.shape
+    out = torch.empty(B, F * (H // 2) * (W // 2), Cin * 4, dtype=bf16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_patchify(x.data_ptr(), out.data_ptr(), B, F, Cin, H, W, _stream()), "ll_patchify")
+    return out
+
+
+def sinusoid(t, dim: int):
+    """t float32 [n] -> bf16 [n, dim]."""
+    _chk(t, "t", torch.float32)
+    n = t.numel()
+    out = torch.empty(n, dim, dtype=bf16, device=t.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_sinusoid(t.data_ptr(), out.data_ptr(), n, dim, _stream()), "ll_sinusoid")
+    return out
+
+
+def unpatchify_x0(head, xt, sigma) -> Tuple[torch.Tensor, torch.Tensor]:
+    """head [B, F*h*w, 4*Cout]; xt [B,F,Cout,H,W]; sigma float32 [B*F] -> (flow, x0) [B,F,Cout,H,W]."""
+    _chk(head, "head"); _chk(xt, "xt"); _chk(sigma, "sigma", torch.float32)
+    B, F, Cout, H, W = xt.shape
+    assert head.shape == (B, F * (H // 2) * (W // 2), 4 * Cout), head.shape
+    assert sigma.numel() == B * F
+    flow, x0 = torch.empty_like(xt), torch.empty_like(xt)
+    lib = _lib.load()
+    _lib.check(lib.ll_unpatchify_x0(head.data_ptr(), xt.data_ptr(), sigma.data_ptr(), flow.data_ptr(), x0.data_ptr(),
+                                    B, F, Cout, H, W, _stream()), "ll_unpatchify_x0")
+    return flow, x0
+
+
+def add_noise(x0, noise, sigma):
+    """x0, noise [N, ...]; sigma float32 [N] -> bf16((1-sigma) x0 + sigma noise)."""
+    _chk(x0, "x0"); _chk(noise, "noise"); _chk(sigma, "sigma", torch.float32)
+    N = x0.shape[0]
+    assert noise.shape == x0.shape and sigma.numel() == N
+    out = torch.empty_like(x0)
+    lib = _lib.load()
+    _lib.check(lib.ll_add_noise(x0.data_ptr(), noise.data_ptr(), sigma.data_ptr(), out.data_ptr(), N,
+                                x0.numel() // N, _stream()), "ll_add_noise")
+    return out
+
+
+def sigma_lookup(t, timesteps, sigmas):
+    """t float32 [n] (device) -> sigmas[argmin |timesteps - t|] float32 [n]."""
+    _chk(t, "t", torch.float32); _chk(timesteps, "timesteps", torch.float32); _chk(sigmas, "sigmas", torch.float32)
+    assert timesteps.numel() == sigmas.numel()
+    out = torch.empty(t.numel(), dtype=torch.float32, device=t.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_sigma_lookup(t.data_ptr(), timesteps.data_ptr(), sigmas.data_ptr(), out.data_ptr(), t.numel(),
+                                   timesteps.numel(), _stream()), "ll_sigma_lookup")
+    return out

@@ -1,0 +1,49 @@
+"""FlowMatchScheduler as used on the inference path (utils/scheduler.py:106-176 with the arguments of
+utils/wan_wrapper.py:141-144: shift=timestep_shift, sigma_min=0, extra_one_step=True, set_timesteps(1000)).
+
+The table is host data (1000 fp32 entries); add_noise runs in a HIP kernel on the device tables."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FlowMatchScheduler:
+    def __init__(self, shift: float = 5.0, sigma_min: float = 0.0, sigma_max: float = 1.0,
+                 num_train_timesteps: int = 1000, num_inference_steps: int = 1000, extra_one_step: bool = True):
+        self.shift, self.sigma_min, self.sigma_max = shift, sigma_min, sigma_max
+        self.num_train_timesteps = num_train_timesteps
+        self.extra_one_step = extra_one_step
+        self.set_timesteps(num_inference_steps)
+
+    def set_timesteps(self, num_inference_steps: int = 1000, denoising_strength: float = 1.0, training: bool = False):
+        """utils/scheduler.py:118-133 (fp32, CPU)."""
+        start = self.sigma_min + (self.sigma_max - self.sigma_min) * denoising_strength
+        if self.extra_one_step:
+            sig = torch.linspace(start, self.sigma_min, num_inference_steps + 1)[:-1]
+        else:
+            sig = torch.linspace(start, self.sigma_min, num_inference_steps)
+        self.sigmas = self.shift * sig / (1 + (self.shift - 1) * sig)
+        self.timesteps = self.sigmas * self.num_train_timesteps
+        self._dev = {}
+
+    def tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.timesteps.to(device=device, dtype=torch.float32).contiguous(),
+                              self.sigmas.to(device=device, dtype=torch.float32).contiguous())
+        return self._dev[key]
+
+    def sigma_of(self, timestep: torch.Tensor) -> torch.Tensor:
+        """sigmas[argmin |timesteps - t|] on the device, float32 [numel]."""
+        ts, sg = self.tables(timestep.device)
+        return ops.sigma_lookup(timestep.reshape(-1).to(torch.float32).contiguous(), ts, sg)
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+        """utils/scheduler.py:159-176: (1 - sigma) * x0 + sigma * noise, per leading index, result in noise.dtype."""
+        if timestep.ndim == 2:
+            timestep = timestep.flatten(0, 1)
+        sigma = self.sigma_of(timestep.to(noise.device))
+        return ops.add_noise(original_samples.to(torch.bfloat16).contiguous(), noise.to(torch.bfloat16).contiguous(),
+                             sigma).type_as(noise)

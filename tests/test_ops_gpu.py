@@ -1,0 +1,231 @@
+"""Parity of every HIP kernel (called through the C ABI via longlive_amd.ops) against the CPU oracle on the same
+seeded inputs.  Elementwise kernels reproduce the reference's bf16 rounding points, so they are held to <= 1 bf16
+ulp with >= 99% of elements bit-exact; MFMA kernels (fp32 accumulation in a different order) to stated tolerances."""
+import math
+
+import pytest
+import torch
+
+from longlive_amd import synth
+from oracle import ref_ops as R
+from util import assert_bf16_close, bf, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from longlive_amd import ops as o
+    return o
+
+
+def hn(name, shape, scale=1.0, shift=0.0, seed=101):
+    return (synth.hash_normal(seed, name, shape) * scale + shift).to(bf)
+
+
+@pytest.mark.parametrize("C,F,fs,B", [(1536, 3, 40, 1), (256, 2, 24, 2), (1536, 1, 7, 2)])
+def test_ln_modulate(ops, C, F, fs, B):
+    x = hn("x", (B, F * fs, C), 1.7, 0.3)
+    e = hn("e", (B, F, 6, C), 0.5)
+    mod = hn("mod", (1, 6, C), 1 / math.sqrt(C))
+    ec = (mod.unsqueeze(1) + e).chunk(6, dim=2)                      # causal_model.py:440
+    for sh, sc in ((0, 1), (3, 4)):
+        want = R.ln_modulate(x, ec[sc], ec[sh], F, 1e-6)
+        got = ops.ln_modulate(x.to(DEV), e.to(DEV), mod.view(6, C).to(DEV), sh, sc, F, 1e-6)
+        assert_bf16_close(got, want, 1, 0.99, f"ln_modulate {sh},{sc}")
+
+
+@pytest.mark.parametrize("C,rows", [(1536, 130), (256, 7)])
+def test_layernorm_affine_and_rmsnorm(ops, C, rows):
+    x = hn("x2", (rows, C), 2.0, -0.2)
+    w = hn("w", (C,), 0.1, 1.0)
+    b = hn("b", (C,), 0.1)
+    assert_bf16_close(ops.layernorm_affine(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6), R.layer_norm(x, 1e-6, w, b), 1, 0.99,
+                      "layernorm_affine")
+    assert_bf16_close(ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6), R.rms_norm(x, w, 1e-6), 1, 0.99, "rmsnorm")
+    # strided input (column slice of a wider buffer)
+    wide = hn("wide", (rows, 2 * C))
+    got = ops.rmsnorm(wide.to(DEV)[:, :C], w.to(DEV), 1e-6)
+    assert_bf16_close(got, R.rms_norm(wide[:, :C], w, 1e-6), 1, 0.99, "rmsnorm strided")
+
+
+@pytest.mark.parametrize("B,F,hp,wp,H,start_frame,ws,ro,wl", [
+    (1, 3, 4, 6, 12, 0, 0, 0, 72),        # direct insert at slot 0
+    (2, 2, 4, 6, 2, 5, 24, 0, 48),        # later frames, batch 2
+    (1, 2, 3, 5, 12, 959, 15, 15, 15),    # recompute with sink protection: first 15 tokens not written
+    (1, 1, 30, 52, 12, 7, 100, 0, 1560),  # real frame geometry
+])
+def test_qk_norm_rope_kv_store(ops, B, F, hp, wp, H, start_frame, ws, ro, wl):
+    D = 128
+    C = H * D
+    fs = hp * wp
+    L = F * fs
+    S = ws + wl + 11
+    qkv = hn("qkv", (B, L, 3 * C), 1.3)
+    wq, wk = hn("wq", (C,), 0.1, 1.0), hn("wk", (C,), 0.1, 1.0)
+    freqs = R.make_freqs(D)
+    q, k, v = qkv.split(C, dim=-1)
+    rq = R.causal_rope_apply(R.rms_norm(q, wq, 1e-6).view(B, L, H, D), (F, hp, wp), freqs, start_frame)
+    rk = R.causal_rope_apply(R.rms_norm(k, wk, 1e-6).view(B, L, H, D), (F, hp, wp), freqs, start_frame)
+    ck0 = hn("ck", (B, S, H, D))
+    cv0 = hn("cv", (B, S, H, D))
+    ck, cv = ck0.clone(), cv0.clone()
+    ck[:, ws:ws + wl] = rk[:, ro:ro + wl]
+    cv[:, ws:ws + wl] = v.reshape(B, L, H, D)[:, ro:ro + wl]
+
+    from longlive_amd.model import CausalWanModelHIP
+    m = CausalWanModelHIP(synth.toy_config(num_layers=1), device=DEV)
+    rope_f, rope_hw = m._rope_tables(hp, wp, DEV)
+    q_out = torch.empty(B, L, C, dtype=bf, device=DEV)
+    gk, gv = ck0.to(DEV), cv0.to(DEV)
+    ops.qk_norm_rope_kv_store(qkv.to(DEV), wq.to(DEV), wk.to(DEV), rope_f, rope_hw, q_out, gk, gv, D, fs, start_frame,
+                              ws, ro, wl, 1e-6)
+    assert_bf16_close(q_out.view(B, L, H, D), rq, 1, 0.99, "roped q")
+    assert_bf16_close(gk, ck, 1, 0.99, "cache k")
+    assert torch.equal(gv.cpu(), cv), "cache v must be a bit-exact copy"
+    # slots outside the write window are untouched
+    mask = torch.ones(S, dtype=torch.bool); mask[ws:ws + wl] = False
+    assert torch.equal(gk.cpu()[:, mask], ck0[:, mask])
+
+
+@pytest.mark.parametrize("B,S,dst,src,n", [(1, 40, 8, 12, 20), (2, 64, 4, 20, 30), (1, 50, 3, 4, 40), (1, 30, 0, 29, 1)])
+def test_kv_roll(ops, B, S, dst, src, n):
+    k0, v0 = hn("rk", (B, S, 2, 128)), hn("rv", (B, S, 2, 128))
+    k, v = k0.clone(), v0.clone()
+    k[:, dst:dst + n] = k0[:, src:src + n]
+    v[:, dst:dst + n] = v0[:, src:src + n]
+    gk, gv = k0.to(DEV), v0.to(DEV)
+    ops.kv_roll(gk, gv, dst, src, n)
+    assert torch.equal(gk.cpu(), k) and torch.equal(gv.cpu(), v)
+
+
+def _lin_ref(x, w, b):
+    return x.double() @ w.double().t() + b.double()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (4680, 1536, 1536), (130, 4608, 1536), (257, 1536, 8960),
+                                   (72, 64, 1536), (1, 128, 64), (512, 1536, 4096)])
+def test_gemm_bias(ops, M, N, K):
+    x, w, b = hn("gx", (M, K)), hn("gw", (N, K), 1 / math.sqrt(K)), hn("gb", (N,), 0.1)
+    got = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+    ref = _lin_ref(x, w, b)
+    # fp32 accumulation in a different order than any CPU GEMM: hold to 1 bf16 ulp of the fp64 result
+    err = (got.double() - ref).abs()
+    tol = ref.abs() * 2 ** -7 + 1e-3
+    assert (err <= tol).all(), f"max err {err.max()} at |ref| {ref.abs().flatten()[err.argmax()]}"
+    assert rel_l2(got, ref) < 3e-3
+    # and agree with the oracle's own bf16 linear about as well as bf16 allows
+    want = torch.nn.functional.linear(x, w, b)
+    assert_bf16_close(got, want, 1, 0.97, "gemm vs F.linear bf16")
+
+
+def test_gemm_epilogues(ops):
+    B, F, fs, C, Nf = 2, 3, 24, 256, 512
+    M = B * F * fs
+    x = hn("ex", (B, F * fs, C))
+    w1, b1 = hn("ew1", (Nf, C), 1 / 16), hn("eb1", (Nf,), 0.1)
+    w2, b2 = hn("ew2", (C, Nf), 1 / 22), hn("eb2", (C,), 0.1)
+    e = hn("ee", (B, F, 6, C), 0.5)
+    mod = hn("emod", (1, 6, C), 0.1)
+    res = hn("eres", (B, F * fs, C))
+    ec = (mod.unsqueeze(1) + e).chunk(6, dim=2)
+    # GELU epilogue (causal_model.py:406-408)
+    h = torch.nn.functional.gelu(torch.nn.functional.linear(x, w1, b1), approximate="tanh")
+    gh = ops.gemm(x.to(DEV), w1.to(DEV), b1.to(DEV), ops.EPI_BIAS_GELU)
+    assert_bf16_close(gh, h, 2, 0.97, "gemm+gelu")   # v_exp/v_rcp sigmoid form of tanh-GELU: <= 2 ulp
+    # gate-residual epilogue (causal_model.py:467): x + (y.unflatten(1,(F,fs)) * e[5]).flatten(1,2)
+    y = torch.nn.functional.linear(h, w2, b2)
+    want = res + (y.unflatten(1, (F, fs)) * ec[5]).flatten(1, 2)
+    got = ops.gemm(h.to(DEV), w2.to(DEV), b2.to(DEV), ops.EPI_BIAS_GATE_RES, res=res.to(DEV), e=e.to(DEV),
+                   mod=mod.view(6, C).to(DEV), gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
+    assert_bf16_close(got, want, 1, 0.97, "gemm+gate-residual")
+    # in-place residual (out aliases res) and plain residual epilogue (causal_model.py:460)
+    r2 = res.to(DEV).clone()
+    ops.gemm(h.to(DEV), w2.to(DEV), b2.to(DEV), ops.EPI_BIAS_RES, out=r2, res=r2)
+    assert_bf16_close(r2, res + y, 1, 0.97, "gemm+residual in place")
+
+
+def test_linear_small_time_embedding(ops):
+    C, fd = 256, 256
+    t = torch.tensor([1000.0, 937.5, 833.3333, 625.0, 0.0, 3.0, 17.0, 999.0, 500.0, 250.0, 42.0, 7.0])   # 12 rows > 8
+    emb = R.sinusoidal_embedding_1d(fd, t).to(bf)
+    got_emb = ops.sinusoid(t.to(DEV), fd)
+    assert_bf16_close(got_emb, emb, 1, 0.98, "sinusoid")
+    w0, b0 = hn("tw0", (C, fd), 0.05), hn("tb0", (C,), 0.02)
+    w2, b2 = hn("tw2", (C, C), 0.05), hn("tb2", (C,), 0.02)
+    w3, b3 = hn("tw3", (6 * C, C), 0.05), hn("tb3", (6 * C,), 0.02)
+    lin, silu = torch.nn.functional.linear, torch.nn.functional.silu
+    e_ref = lin(silu(lin(emb, w0, b0)), w2, b2)
+    e0_ref = lin(silu(e_ref), w3, b3)
+    d = lambda a: a.to(DEV)
+    h = ops.linear_small(d(emb), d(w0), d(b0), act_out=1)
+    e = ops.linear_small(h, d(w2), d(b2))
+    e0 = ops.linear_small(e, d(w3), d(b3), act_in=1)
+    assert_bf16_close(e, e_ref, 2, 0.90, "time e")
+    assert_bf16_close(e0, e0_ref, 2, 0.85, "time e0")
+
+
+@pytest.mark.parametrize("B,Lq,H,Sk,segs", [
+    (1, 40, 2, 72, [(0, 72)]),
+    (2, 200, 2, 300, [(0, 64), (100, 300)]),          # sink + non-adjacent window, both with ragged tails
+    (1, 130, 12, 512, [(0, 512)]),                      # cross-attention shape
+    (1, 1560, 12, 4680, [(0, 1560), (1560, 4680)]),     # adjacent ranges merge; real head count
+    (1, 33, 1, 7, [(0, 7)]),                            # fewer keys than one tile
+])
+def test_flash_attn(ops, B, Lq, H, Sk, segs):
+    q = hn("aq", (B, Lq, H, 128))
+    k = hn("ak", (B, Sk, H, 128))
+    v = hn("av", (B, Sk, H, 128), 0.7)
+    kk = torch.cat([k[:, a:b] for a, b in segs], 1)
+    vv = torch.cat([v[:, a:b] for a, b in segs], 1)
+    exact = R.attention_exact(q, kk, vv)
+    oracle = R.attention(q, kk, vv).double()
+    got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), segs).cpu().double()
+    err, oerr = (got - exact).abs().max().item(), (oracle - exact).abs().max().item()
+    assert err < 1.2e-2, f"max abs err vs fp64 {err} (oracle's own bf16 path: {oerr})"
+    assert rel_l2(got, exact) < 6e-3, (rel_l2(got, exact), rel_l2(oracle, exact))
+
+
+def test_flash_attn_online_softmax_rescale(ops):
+    """Forces the running-max update late in the key sequence (a spiked key in the last tile)."""
+    B, Lq, H, Sk = 1, 64, 1, 256
+    q, k, v = hn("sq", (B, Lq, H, 128)), hn("sk", (B, Sk, H, 128)), hn("sv", (B, Sk, H, 128))
+    k[0, 250, 0] = (q[0, 5, 0].float() * 3).to(bf)      # huge score for query 5 at key 250
+    k[0, 3, 0] = (q[0, 9, 0].float() * 3).to(bf)        # and an early spike for query 9
+    exact = R.attention_exact(q, k, v)
+    got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [(0, Sk)]).cpu().double()
+    assert (got - exact).abs().max().item() < 2e-2
+
+
+def test_patchify_unpatchify_x0_add_noise(ops):
+    cfg = synth.toy_config()
+    B, F, Cc, H, W = 2, 3, 16, 8, 12
+    x = hn("px", (B, F, Cc, H, W))
+    w = hn("pw", (64, Cc, 1, 2, 2), 0.2)
+    bias = hn("pb", (64,), 0.1)
+    want = torch.nn.functional.conv3d(x.permute(0, 2, 1, 3, 4), w, bias, stride=(1, 2, 2)).flatten(2).transpose(1, 2)
+    got = ops.gemm(ops.patchify(x.to(DEV)), w.view(64, -1).to(DEV), bias.to(DEV))
+    assert_bf16_close(got, want, 1, 0.97, "patch embedding")
+    # unpatchify + flow -> x0
+    sch = R.FlowMatchSchedulerRef(5.0)
+    head = hn("hd", (B, F * 4 * 6, 64))
+    t = torch.tensor([[1000.0, 937.5, 625.0], [0.0, 833.3333, 500.0]])
+    flow_ref = torch.einsum("bfhwpqrc->bcfphqwr", head.view(B, F, 4, 6, 1, 2, 2, 16)).reshape(B, 16, F, 8, 12)
+    flow_ref = flow_ref.permute(0, 2, 1, 3, 4)
+    x0_ref = R.flow_to_x0(sch, flow_ref.flatten(0, 1), x.flatten(0, 1), t.flatten()).unflatten(0, (B, F))
+    from longlive_amd.scheduler import FlowMatchScheduler
+    ps = FlowMatchScheduler(5.0)
+    assert torch.equal(ps.sigmas, sch.sigmas) and torch.equal(ps.timesteps, sch.timesteps)
+    sigma = ps.sigma_of(t.to(DEV))
+    tid = torch.argmin((sch.timesteps.double().unsqueeze(0) - t.flatten().double().unsqueeze(1)).abs(), dim=1)
+    assert torch.equal(sigma.cpu(), sch.sigmas[tid])
+    flow, x0 = ops.unpatchify_x0(head.to(DEV), x.to(DEV), sigma)
+    assert torch.equal(flow.cpu(), flow_ref)
+    nd = (x0.cpu() != x0_ref).sum().item()
+    assert nd == 0, f"fp64 flow->x0 must be bit-exact: {nd} of {x0_ref.numel()} differ, e.g. {x0.cpu()[x0.cpu() != x0_ref][:4]} vs {x0_ref[x0.cpu() != x0_ref][:4]}"
+    nz = hn("nz", (B * F, Cc, H, W))
+    tt = torch.tensor([937.5, 833.3333, 625.0, 625.0, 0.0, 1000.0])
+    want = sch.add_noise(x0_ref.flatten(0, 1), nz, tt)
+    got = ps.add_noise(x0.flatten(0, 1), nz.to(DEV), tt.to(DEV))
+    assert torch.equal(got.cpu(), want), "add_noise must be bit-exact"
