@@ -254,7 +254,7 @@ class CausalWanModelHIP(nn.Module):
             ops.qk_norm_rope_kv_store(qkv, sa.norm_q.weight, sa.norm_k.weight, rope_f, rope_hw, q_buf.view(B, L, C),
                                       kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
                                       plan.roped_offset, plan.write_len, c.eps)
-            att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments)
+            att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
             ops.gemm(att.view(B, L, C), sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
                      mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
             # --- cross attention (causal_model.py:460; model.py:159-194) ---
@@ -268,7 +268,7 @@ class CausalWanModelHIP(nn.Module):
                 ops.rmsnorm(kc, ca.norm_k.weight, c.eps, out=cac["k"].view(B, c.text_len, C))
                 ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
                 cac["is_init"] = True
-            atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)])
+            atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
             ops.gemm(atc.view(B, L, C), ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
             # --- FFN (causal_model.py:462-468) ---
             h2 = ops.ln_modulate(xs, e0, pk["mod"], 3, 4, F, c.eps)

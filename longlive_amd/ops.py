@@ -20,6 +20,41 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are launched on (bench.py's roofline leg).
+    `ops.timer = KernelTimer()` turns it on; wrappers call timer.around(tag, work) for tagged kernels."""
+
+    def __init__(self, tags=None):
+        self.tags = None if tags is None else set(tags)
+        self.records = {}          # tag -> [(start_event, end_event, work)]
+
+    def begin(self, tag):
+        if self.tags is not None and tag not in self.tags:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, tag, start, work):
+        if start is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.setdefault(tag, []).append((start, ev, work))
+
+    def summary(self):
+        """tag -> dict(launches, avg_ms, total_ms, work_per_launch) (call after a device sync)."""
+        out = {}
+        for tag, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[tag] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                            work_per_launch=sum(w for _, _, w in recs) / len(recs))
+        return out
+
+
+timer: Optional[KernelTimer] = None
+
+
 def _chk(t: torch.Tensor, name: str, dtype=bf16) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a device tensor (longlive_amd has no CPU path)")
@@ -136,9 +171,12 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
         assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
         assert e.numel() == (M // frame_len) * nmod * N, (e.shape, M, frame_len)
     lib = _lib.load()
+    t0 = timer.begin("gemm") if timer is not None else None
     _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                 _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
                "ll_gemm_bf16")
+    if timer is not None:
+        timer.end("gemm", t0, 2.0 * M * N * K)
     return out
 
 
@@ -159,7 +197,7 @@ def linear_small(x, w, bias, act_in: int = 0, act_out: int = 0):
     return out
 
 
-def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None):
+def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None, tag: Optional[str] = None):
     """q [B,Lq,H,128] (contiguous); k,v [B,Sk,H,128]; keys = concatenation of up to two row ranges
     [(start, end), ...] of k/v.  Returns [B,Lq,H,128]."""
     _chk(q, "q"); _chk(k, "k"); _chk(v, "v")
@@ -178,8 +216,15 @@ def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None):
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _lib.load()
+    t0 = None
+    if timer is not None:
+        nkeys = (e0 - s0) + (e1 - s1)
+        tag = tag or "flash_attn"
+        t0 = timer.begin(tag)
     _lib.check(lib.ll_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, H, H * D, H * D,
                                  H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, _stream()), "ll_flash_attn")
+    if timer is not None:
+        timer.end(tag, t0, 4.0 * B * H * Lq * nkeys * D)     # algorithmic FLOPs: QK^T + PV
     return out
 
 

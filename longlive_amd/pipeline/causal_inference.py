@@ -102,6 +102,22 @@ class CausalInferencePipeline(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
+    def stream(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None):
+        """Generator form of `inference`: yields (start_frame, denoised_latents[B, F, 16, h, w]) after every
+        autoregressive block, so frames can be consumed (decoded / displayed / timed) while generation goes on."""
+        batch_size, num_output_frames = noise.shape[:2]
+        assert num_output_frames % self.num_frame_per_block == 0
+        cond = self._encode(text_prompts)
+        self._setup(noise, num_output_frames)
+        nf = self.num_frame_per_block
+        for start in range(0, num_output_frames, nf):
+            denoised = self._denoise_block(noise[:, start:start + nf], cond, start, batch_size, nf)
+            if output is not None:
+                output[:, start:start + nf] = denoised
+            self._clean_context_pass(denoised, cond, start)
+            yield start, denoised
+
+    @torch.no_grad()
     def inference(self, noise: torch.Tensor, text_prompts: List[str], return_latents: bool = False,
                   profile: bool = False, low_memory: bool = False):
         """noise [B, T, 16, H/8, W/8] -> video [B, T', 3, H, W] in [0,1] (None without a VAE) and, with
