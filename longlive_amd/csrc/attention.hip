@@ -20,12 +20,6 @@
 #define KT 64                       // keys per tile
 #define TILE_B (KT * 128 * 2)       // 16 KiB
 
-template <int NW>
-struct AttnStage {                  // per-thread staging registers for one K + one V tile
-  static constexpr int NCHUNK = 1024 / (NW * 64);
-  uint4 k[NCHUNK], v[NCHUNK];
-};
-
 struct Segs {
   int s0, n0, s1, n1, nt0, nt;      // two key ranges and their tile counts
 };
@@ -42,30 +36,25 @@ __device__ __forceinline__ void tile_range(const Segs& sg, int t, int& base, int
   valid = valid < KT ? valid : KT;
 }
 
-template <int NW>
-__device__ __forceinline__ void load_tile(AttnStage<NW>& st, const bf16* __restrict__ kh, const bf16* __restrict__ vh,
-                                          int ldk, int base, int valid, int tid) {
-#pragma unroll
-  for (int i = 0; i < AttnStage<NW>::NCHUNK; ++i) {
-    int cid = tid + i * NW * 64;
-    int key = cid >> 4, ch = cid & 15;
-    int row = base + (key < valid ? key : valid - 1);  // clamp: masked keys re-read the last valid row
-    size_t off = (size_t)row * ldk + ch * 8;
-    st.k[i] = *reinterpret_cast<const uint4*>(kh + off);
-    st.v[i] = *reinterpret_cast<const uint4*>(vh + off);
+// Staging registers are plain unrolled arrays indexed by compile-time constants, and the prefetch is UNCONDITIONAL
+// (the tile index is clamped on the last iteration): a struct passed by reference across an `if (more)` branch was
+// placed in scratch by hipcc, which put an s_waitcnt + scratch_store behind every global load (3x slower kernel).
+#define ATTN_LOAD_TILE(BASE, VALID)                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < NCHUNK; ++i_) {                                        \
+    int cid_ = tid + i_ * NW * 64;                                                               \
+    int key_ = cid_ >> 4, ch_ = cid_ & 15;                                                       \
+    int row_ = (BASE) + (key_ < (VALID) ? key_ : (VALID) - 1); /* masked keys re-read a valid row */ \
+    size_t off_ = (size_t)row_ * ldk + ch_ * 8;                                                  \
+    kr[i_] = *reinterpret_cast<const uint4*>(kh + off_);                                         \
+    vr[i_] = *reinterpret_cast<const uint4*>(vh + off_);                                         \
   }
-}
-
-template <int NW>
-__device__ __forceinline__ void store_tile(const AttnStage<NW>& st, char* kl, char* vl, int tid) {
-#pragma unroll
-  for (int i = 0; i < AttnStage<NW>::NCHUNK; ++i) {
-    int cid = tid + i * NW * 64;
-    int key = cid >> 4, ch = cid & 15;
-    *reinterpret_cast<uint4*>(kl + key * 256 + ((ch ^ (key & 15)) << 4)) = st.k[i];
-    *reinterpret_cast<uint4*>(vl + key * 256 + ((ch ^ ((key & 3) << 2)) << 4)) = st.v[i];
+#define ATTN_STORE_TILE(KL, VL)                                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < NCHUNK; ++i_) {                                        \
+    int cid_ = tid + i_ * NW * 64;                                                               \
+    int key_ = cid_ >> 4, ch_ = cid_ & 15;                                                       \
+    *reinterpret_cast<uint4*>((KL) + key_ * 256 + ((ch_ ^ (key_ & 15)) << 4)) = kr[i_];          \
+    *reinterpret_cast<uint4*>((VL) + key_ * 256 + ((ch_ ^ ((key_ & 3) << 2)) << 4)) = vr[i_];    \
   }
-}
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
@@ -100,11 +89,12 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __re
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  AttnStage<NW> st;
+  constexpr int NCHUNK = 1024 / (NW * 64);
+  uint4 kr[NCHUNK], vr[NCHUNK];
   int base, valid;
   tile_range(sg, 0, base, valid);
-  load_tile<NW>(st, kh, vh, ldk, base, valid, tid);
-  store_tile<NW>(st, smem, smem + TILE_B, tid);
+  ATTN_LOAD_TILE(base, valid);
+  ATTN_STORE_TILE(smem, smem + TILE_B);
   __syncthreads();
 
   // per-lane LDS offsets
@@ -116,10 +106,10 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __re
     const char* kl = smem + (t & 1) * 2 * TILE_B;
     const char* vl = kl + TILE_B;
     int cur_valid = valid;
-    const bool more = (t + 1 < sg.nt);
-    if (more) {
-      tile_range(sg, t + 1, base, valid);
-      load_tile<NW>(st, kh, vh, ldk, base, valid, tid);  // global -> regs, consumed after this tile's MFMAs
+    {
+      int tn = t + 1 < sg.nt ? t + 1 : t;               // clamped: the last iteration re-fetches its own tile
+      tile_range(sg, tn, base, valid);
+      ATTN_LOAD_TILE(base, valid);                      // global -> regs, consumed after this tile's MFMAs
     }
 
     // ---- S^T = K Q^T : 2 key blocks x 8 k-steps ------------------------------------------------------------
@@ -169,11 +159,13 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __re
       }
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
+    if (__any(m_new != m_run)) {   // wave-uniform; exact: alpha == 1 for every lane otherwise
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
     m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
 
     // P^T fragments (B operand): k-step (kb, s2) uses accumulator registers 8 s2 .. 8 s2 + 7 of s[kb]
     bf16x8 pf[2][2];
@@ -207,9 +199,9 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __re
       }
     }
 
-    if (more) {
-      char* nk = smem + ((t + 1) & 1) * 2 * TILE_B;
-      store_tile<NW>(st, nk, nk + TILE_B, tid);
+    {
+      char* nk = smem + ((t + 1) & 1) * 2 * TILE_B;     // other stage: last read one barrier ago
+      ATTN_STORE_TILE(nk, nk + TILE_B);
     }
     __syncthreads();
   }
