@@ -139,12 +139,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.timer = None
-    if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    frames = world * args.steps * 3 * PIXEL_FRAMES_PER_LATENT
+    from longlive_amd.replicas import aggregate_throughput
+    frames, elapsed = aggregate_throughput(args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed, device=dev)
     fps = frames / elapsed
     out = {
         "metric": "generated frames/sec (832x480) LongLive-1.3B, frame-sink + short-window attention, 4 denoise steps + clean-context pass",

@@ -344,11 +344,80 @@ def gen_real_fwd(ns):
 
 def main(argv):
     ns = load_pipelines()
-    todo = argv or ["ops", "toy", "pipe", "real_block", "real_fwd"]
+    todo = argv or ["ops", "toy", "pipe", "pipe_calls", "real_block", "real_fwd"]
     for t in todo:
         t0 = time.time()
         globals()["gen_" + t](ns)
         print(f"[{t}] {time.time() - t0:.1f}s")
+
+
+
+
+# --------------------------------------------------------------------------------------------
+class FakeGenerator(nn.Module):
+    """Records every generator call a pipeline makes and returns a cheap deterministic x0 (no model).
+    Shared by the golden generator (driving the REFERENCE pipelines) and tests/test_pipeline_host.py (driving
+    longlive_amd's pipelines): the two call logs must be identical."""
+
+    def __init__(self, scheduler, frame_seq_length):
+        super().__init__()
+        self.dummy = nn.Parameter(torch.zeros(1))
+        self.scheduler = scheduler
+        self.log = []
+        self.model = SimpleNamespace(num_frame_per_block=1, local_attn_size=-1, max_attention_size=0, block_mask=None,
+                                     named_modules=lambda: [], _prepare_blockwise_causal_attn_mask=lambda **kw: None)
+        self.fs = frame_seq_length
+
+    def get_scheduler(self):
+        return self.scheduler
+
+    def forward(self, noisy_image_or_video, conditional_dict, timestep, kv_cache=None, crossattn_cache=None,
+                current_start=None, sink_recache_after_switch=False, **kw):
+        x = noisy_image_or_video
+        self.log.append(dict(t=[round(float(v), 4) for v in timestep.flatten().tolist()], cs=int(current_start),
+                             recache=bool(sink_recache_after_switch), prompt=conditional_dict["name"],
+                             frames=int(x.shape[1]), xsum=round(float(x.float().sum()), 3),
+                             kv_zero=bool(kv_cache[0]["k"].abs().sum() == 0),
+                             ca_init=bool(crossattn_cache[0]["is_init"]), n_layers=len(kv_cache),
+                             kv_shape=list(kv_cache[0]["k"].shape)))
+        # mimic the model's side effects on the caches that the pipelines depend on
+        cs, n = int(current_start), x.shape[1] * self.fs
+        kv_cache[0]["k"][:, : min(n, kv_cache[0]["k"].shape[1])] += 1
+        crossattn_cache[0]["is_init"] = True
+        x0 = (0.5 * x.float() + 0.01 * (len(self.log) % 7)).to(x.dtype)
+        return x0, x0
+
+
+def gen_pipe_calls(ns):
+    sch = ns.scheduler.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    cfg = synth.WanConfig(lat_h=4, lat_w=4)          # 4 tokens per frame; heads stay 12 x 128 (hard-coded upstream)
+    args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                           num_frame_per_block=3, context_noise=0, global_sink=False)
+    enc = lambda text_prompts: {"prompt_embeds": torch.zeros(1, 1), "name": text_prompts[0]}
+    rec = {}
+    real = torch.randn_like
+    try:
+        for tag, gs, T, switches in (("single", True, 21, None), ("inter_gs0", False, 48, [10, 16, 40]),
+                                     ("inter_gs1", True, 30, [0, 20])):
+            args.global_sink = gs
+            fg = FakeGenerator(sch, 4)
+            noise = synth.synth_noise(cfg, T, seed=3)
+            torch.randn_like = _HashRandn(5)
+            if switches is None:
+                P = ns.causal_inference.CausalInferencePipeline(args, "cpu", generator=fg, text_encoder=enc, vae=_FakeVAE())
+                P.num_transformer_blocks, P.frame_seq_length = 2, 4
+                _, lat = P.inference(noise, ["p0"], return_latents=True)
+            else:
+                P = ns.interactive.InteractiveCausalInferencePipeline(args, "cpu", generator=fg, text_encoder=enc, vae=_FakeVAE())
+                P.num_transformer_blocks, P.frame_seq_length = 2, 4
+                prompts = [[f"p{i}"] for i in range(len(switches) + 1)]
+                _, lat = P.inference(noise, text_prompts_list=prompts, switch_frame_indices=switches, return_latents=True)
+            rec[tag] = dict(log=fg.log, latents=lat.clone(), T=T, switches=switches, global_sink=gs)
+    finally:
+        torch.randn_like = real
+    _save("pipe_calls.pt", rec)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads without a GPU, exports every symbol that
+include/longlive_hip.h declares, the ctypes table matches the header's parameter counts, and argument validation
+fails loudly (status code + message) BEFORE anything is launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from longlive_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "longlive_hip.h")).read()
+
+
+def _declarations():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(ll_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    decls = _declarations()
+    assert len(decls) >= 15
+    for name in decls:
+        assert hasattr(lib, name), f"{name} declared in include/longlive_hip.h but not exported"
+    assert lib.ll_version() >= 100
+
+
+def test_ctypes_table_matches_header():
+    decls = _declarations()
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    for name, n in decls.items():
+        assert len(_lib.SIGNATURES[name]) == n, f"{name}: header has {n} parameters, ctypes table {len(_lib.SIGNATURES[name])}"
+
+
+def test_no_torch_types_in_the_abi():
+    code = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)          # comments may mention torch; declarations may not
+    assert "torch" not in code and "at::" not in code and "#include <hip" not in code
+    assert re.findall(r"#include\s*<([^>]+)>", code) == ["stdint.h"]
+
+
+@pytest.mark.parametrize("call,needle", [
+    (lambda L: L.ll_gemm_bf16(0, 0, 1, 0, 128, 128, 100, 100, 128, 0, 0, 0, 0, 0, 0, 0, 0, None), "K=100"),
+    (lambda L: L.ll_gemm_bf16(0, 0, 0, 0, 128, 128, 128, 128, 128, 0, 0, 0, 0, 0, 0, 0, 0, None), "bias"),
+    (lambda L: L.ll_gemm_bf16(0, 0, 1, 0, 128, 128, 128, 128, 128, 7, 0, 0, 0, 0, 0, 0, 0, None), "epilogue"),
+    (lambda L: L.ll_ln_modulate(0, 0, 0, 0, 6, 0, 1, 1, 10, 1536, 3, 1e-6, None), "not divisible"),
+    (lambda L: L.ll_ln_modulate(0, 0, 0, 0, 6, 0, 1, 1, 9, 4096, 3, 1e-6, None), "C=4096"),
+    (lambda L: L.ll_kv_roll(0, 0, 1, 100, 1536, 10, 5, 20, None), "src > dst"),
+    (lambda L: L.ll_kv_roll(0, 0, 1, 100, 1536, 5, 90, 20, None), "outside cache"),
+    (lambda L: L.ll_qk_norm_rope_kv_store(0, 0, 0, 0, 0, 0, 0, 0, 1, 4680, 1536, 128, 1560, 1023, 18720, 0, 0, 4680, 1e-6, None), "RoPE table"),
+    (lambda L: L.ll_qk_norm_rope_kv_store(0, 0, 0, 0, 0, 0, 0, 0, 1, 4680, 1536, 128, 1560, 0, 18720, 18000, 0, 4680, 1e-6, None), "outside cache"),
+    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 0, 0, 0, 0.088, None), "non-empty"),
+    (lambda L: L.ll_linear_small(0, 0, 0, 0, 9, 64, 64, 0, 0, None), "M=9"),
+])
+def test_invalid_arguments_are_rejected_before_launch(call, needle):
+    lib = _lib.load()
+    rc = call(lib)
+    assert rc == -1, rc                       # LL_ERR_INVALID_ARG
+    msg = lib.ll_last_error().decode()
+    assert needle in msg, msg
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "test")
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: handing the product path a host tensor is an error, not a silent slow path."""
+    import torch
+    from longlive_amd import ops
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.gemm(x, x, x[0])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.layernorm_affine(x, x[0], x[0], 1e-6)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
