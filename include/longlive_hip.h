@@ -42,6 +42,8 @@ enum ll_epilogue {
 
 int ll_version(void);
 const char* ll_last_error(void);
+/* Development knob for A/B timing of kernel variants (tools/kbench); the defaults are the shipped configuration. */
+int ll_set_tuning(const char* key, int value);
 
 /* ---- norms / modulation ------------------------------------------------------------------------------------- */
 

@@ -17,6 +17,7 @@ _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "ll_version": [],
     "ll_last_error": [],
+    "ll_set_tuning": [C.c_char_p, _i],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ll_rmsnorm": [_p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -223,6 +223,263 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __re
   }
 }
 
+// =================================================================================================================
+// Software-pipelined variant (single contiguous key range -- the LongLive steady state and cross-attention).
+//
+// Inside ONE wave the matrix pipe and the VALU run concurrently (an MFMA occupies the issue port for 8 of its 32
+// cycles), but a tile's own chain QK^T -> softmax -> PV is serial.  So iteration t overlaps two different tiles:
+//     phase A:  S(t+1) = K(t+1) Q^T        [16 MFMA + 16 ds_read_b128]   ||   softmax of S(t) -> P(t)      [VALU]
+//     phase B:  O^T   += V(t)^T P(t)^T     [16 MFMA + 32 ds_read_b64_tr] ||   stage tile t+2 into LDS      [ds_write]
+// one barrier per tile.  K(t+1) is read in iteration t and V(t) in iteration t, so K lives in a 2-stage ring and V in a
+// 3-stage ring (tile t+2 may be written while V(t) is still being read by slower waves).  Row reductions use
+// v_permlane32_swap (VALU) instead of ds_bpermute so the softmax never waits on LDS.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  f32x2 v = {a, b};
+  bf16x2 r = __builtin_convertvector(v, bf16x2);   // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, r);
+}
+
+#ifdef LL_XHALF_SHFL
+__device__ __forceinline__ float xhalf_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+__device__ __forceinline__ float xhalf_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+#else
+__device__ __forceinline__ float xhalf_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+#endif
+
+#define PIPE_KSTAGES 2
+#define PIPE_VSTAGES 3
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
+                                                                     const bf16* __restrict__ Vc, bf16* __restrict__ O,
+                                                                     int Lq, int ldq, int ldo, int ldk,
+                                                                     long long k_batch_stride, int kstart, int nkeys,
+                                                                     float c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K stage 0,1][V stage 0,1,2] x 16 KiB
+  char* const ksm = smem;
+  char* const vsm = smem + PIPE_KSTAGES * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  const int nt = (nkeys + KT - 1) / KT;
+  const int last_valid = nkeys - (nt - 1) * KT;
+
+  const bf16* kh = Kc + (size_t)b * k_batch_stride + (size_t)kstart * ldk + head * 128;
+  const bf16* vh = Vc + (size_t)b * k_batch_stride + (size_t)kstart * ldk + head * 128;
+
+  bf16x8 qf[8];
+  {
+    int qr = q0 + r;
+    qr = qr < Lq ? qr : Lq - 1;
+    const bf16* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 128 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+  }
+
+  constexpr int NCHUNK = 1024 / (NW * 64);
+  uint4 kr[NCHUNK], vr[NCHUNK];
+  // per-thread staging coordinates (loop invariant)
+  int st_goff[NCHUNK], st_koff[NCHUNK], st_voff[NCHUNK], st_key[NCHUNK];
+#pragma unroll
+  for (int i = 0; i < NCHUNK; ++i) {
+    int cid = tid + i * NW * 64;
+    int key = cid >> 4, ch = cid & 15;
+    st_key[i] = key;
+    st_goff[i] = ch * 8;
+    st_koff[i] = key * 256 + ((ch ^ (key & 15)) << 4);
+    st_voff[i] = key * 256 + ((ch ^ ((key & 3) << 2)) << 4);
+  }
+#define PIPE_LOAD(T)                                                                             \
+  {                                                                                              \
+    int t_ = (T) < nt ? (T) : nt - 1;                                                            \
+    int valid_ = (t_ == nt - 1) ? last_valid : KT;                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < NCHUNK; ++i_) {                                      \
+      int key_ = st_key[i_] < valid_ ? st_key[i_] : valid_ - 1;                                  \
+      size_t off_ = (size_t)(t_ * KT + key_) * ldk + st_goff[i_];                                \
+      kr[i_] = *reinterpret_cast<const uint4*>(kh + off_);                                       \
+      vr[i_] = *reinterpret_cast<const uint4*>(vh + off_);                                       \
+    }                                                                                            \
+  }
+#define PIPE_STORE(KS, VS)                                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < NCHUNK; ++i_) {                                        \
+    *reinterpret_cast<uint4*>(ksm + (KS) * TILE_B + st_koff[i_]) = kr[i_];                       \
+    *reinterpret_cast<uint4*>(vsm + (VS) * TILE_B + st_voff[i_]) = vr[i_];                       \
+  }
+
+  // per-lane LDS read offsets (loop invariant; the stage base is added per iteration)
+  int k_off[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) << 4);   // + 8192 for kb = 1
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+  int v_off[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    int dbyte = (32 * db + 16 * tg1 + 4 * tp) * 2;
+    v_off[db] = (4 * h + tq) * 256 + (((dbyte >> 4) ^ (tq << 2)) << 4) + (dbyte & 15);   // + (32kb+16s2[+8])*256
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // ---- prologue: tiles 0 and 1 into LDS, S(0) ------------------------------------------------------------------
+  PIPE_LOAD(0);
+  PIPE_STORE(0, 0);
+  PIPE_LOAD(1);
+  PIPE_STORE(1, 1);
+  __syncthreads();
+  f32x16 s_cur[2], s_nxt[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_cur[kb][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 kf = *reinterpret_cast<const bf16x8*>(ksm + k_off[ks] + kb * 8192);
+      s_cur[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_cur[kb], 0, 0, 0);
+    }
+  __syncthreads();   // K stage 0 is overwritten by iteration 0's staging: every wave must be done reading it
+
+  int vstage = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* kn = ksm + ((t + 1) & 1) * TILE_B;       // K(t+1)
+    const char* vc = vsm + vstage * TILE_B;              // V(t)
+    PIPE_LOAD(t + 2);                                    // global -> regs; written to LDS in phase B
+
+    if (t == nt - 1 && last_valid < KT) {                // ragged last tile: mask (uniform branch, own region)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (key >= last_valid) s_cur[kb][i] = -INFINITY;
+        }
+    }
+
+    // ---- phase A: S(t+1) on the matrix pipe  ||  softmax(S(t)) on the VALU --------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_nxt[kb][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kn + k_off[ks] + kb * 8192);
+        s_nxt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_nxt[kb], 0, 0, 0);
+      }
+    float mx = s_cur[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_cur[kb][i]);
+    mx = xhalf_max(mx);
+    float m_new = fmaxf(m_run, mx);
+    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    float mc = m_new * c;
+    float rs = 0.f;
+    uint4 pw[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));
+          rs += p[j];
+        }
+        pw[kb][s2] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]),
+                                pack_bf16x2(p[6], p[7]));
+      }
+    rs = xhalf_sum(rs);
+    l_run = l_run * alpha + rs;
+
+    if (__any(m_new != m_run)) {   // wave-uniform, exact: alpha == 1 in every lane otherwise
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+    m_run = m_new;
+
+    // ---- phase B: O^T += V(t)^T P(t)^T  ||  stage tile t+2 -------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pfrag = __builtin_bit_cast(bf16x8, pw[kb][s2]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const char* a0 = vc + v_off[db] + (32 * kb + 16 * s2) * 256;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 8 * 256));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pfrag, o[db], 0, 0, 0);
+        }
+      }
+    {
+      int vs2 = vstage + 2;
+      vs2 = vs2 >= PIPE_VSTAGES ? vs2 - PIPE_VSTAGES : vs2;
+      PIPE_STORE(t & 1, vs2);      // K(t+2) over K(t) (read an iteration ago), V(t+2) over V(t-1)
+    }
+    __syncthreads();
+    s_cur[0] = s_nxt[0];
+    s_cur[1] = s_nxt[1];
+    vstage = vstage == PIPE_VSTAGES - 1 ? 0 : vstage + 1;
+  }
+
+  int qr = q0 + r;
+  if (qr < Lq) {
+    float inv = 1.0f / l_run;
+    bf16* op = O + ((size_t)b * Lq + qr) * ldo + head * 128 + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 w;
+        w.x = pack_bf16x2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
+        w.y = pack_bf16x2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+        *reinterpret_cast<uint2*>(op + 32 * db + 8 * g4) = w;
+      }
+  }
+}
+
+static int g_attn_variant = 1;   // 0: simple kernel, 1: software-pipelined kernel (single key range)
+void ll_set_attn_variant_internal(int v) { g_attn_variant = v; }
+
+static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B,
+                                         int Lq, int H, int ldq, int ldo, int ldk, long long k_batch_stride, int kstart,
+                                         int nkeys, float c, ll_stream stream) {
+  constexpr int NW = 8;
+  size_t lds = (PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  dim3 grid((Lq + NW * 32 - 1) / (NW * 32), H, B), block(NW * 64);
+  hipLaunchKernelGGL(flash_attn_pipe_kernel<NW>, grid, block, lds, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
+                     (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, kstart, nkeys, c);
+  return ll_check_launch("ll_flash_attn(pipe)");
+}
+
 extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H,
                              int ldq, int ldo, int ldk, long long k_batch_stride, int seg0_start, int seg0_len,
                              int seg1_start, int seg1_len, float scale, ll_stream stream) {
@@ -236,9 +493,12 @@ extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* 
   sg.nt0 = (sg.n0 + KT - 1) / KT;
   sg.nt = sg.nt0 + (sg.n1 + KT - 1) / KT;
   float c = scale * 1.4426950408889634f;
+  if (g_attn_variant == 1 && sg.n1 == 0)
+    return flash_attn_pipe_launch(q, k, v, out, B, Lq, H, ldq, ldo, ldk, k_batch_stride, sg.s0, sg.n0, c, stream);
   constexpr int NW = 4;
   dim3 grid((Lq + NW * 32 - 1) / (NW * 32), H, B), block(NW * 64);
   hipLaunchKernelGGL(flash_attn_kernel<NW>, grid, block, 4 * TILE_B, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
                      (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, sg, c);
   return ll_check_launch("ll_flash_attn");
 }
+

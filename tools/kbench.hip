@@ -1,0 +1,182 @@
+// Standalone kernel micro-benchmark for liblonglive_hip.so (no Python, no torch): times the MFMA kernels at the real
+// LongLive-1.3B shapes with HIP events and spot-checks a sample of outputs against a host fp64 reference.
+//   hipcc --offload-arch=gfx950 -O2 tools/kbench.hip -Iinclude -Llonglive_amd -llonglive_hip -Wl,-rpath,$PWD/longlive_amd -o tools/kbench
+//   tools/kbench [gemm|attn|all] [iters]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+#include <vector>
+
+#include "longlive_hip.h"
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));    \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+#define LL(x)                                                       \
+  do {                                                              \
+    int r_ = (x);                                                   \
+    if (r_ != 0) {                                                  \
+      fprintf(stderr, "%s -> %d: %s\n", #x, r_, ll_last_error());   \
+      exit(1);                                                      \
+    }                                                               \
+  } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint64_t rnd() {
+  uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static inline float gauss() {  // Irwin-Hall(12)
+  float s = 0;
+  for (int i = 0; i < 3; ++i) {
+    uint64_t h = rnd();
+    for (int k = 0; k < 4; ++k) s += (float)((h >> (16 * k)) & 0xFFFF);
+  }
+  return (s - 393210.f) / 65536.f;
+}
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFF + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct Buf {
+  std::vector<uint16_t> h;
+  uint16_t* d = nullptr;
+  Buf(size_t n, float scale) : h(n) {
+    for (size_t i = 0; i < n; ++i) h[i] = f2bf(gauss() * scale);
+    CK(hipMalloc(&d, n * 2));
+    CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+  }
+  void pull() { CK(hipMemcpy(h.data(), d, h.size() * 2, hipMemcpyDeviceToHost)); }
+  ~Buf() { hipFree(d); }
+};
+
+static double time_ms(hipStream_t s, int iters, const std::function<void()>& fn) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) fn();
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) fn();
+  CK(hipEventRecord(b, s));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+static void bench_gemm(const char* name, int M, int N, int K, int epi, int iters) {
+  Buf x((size_t)M * K, 1.0f), w((size_t)N * K, 1.0f / sqrtf((float)K)), bias(N, 0.1f), out((size_t)M * N, 0.f);
+  Buf res((size_t)M * N, 1.0f), e((size_t)3 * 6 * N, 0.5f), mod((size_t)6 * N, 0.1f);
+  hipStream_t s = 0;
+  auto fn = [&]() {
+    LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, M, N, K, K, N, epi, res.d, e.d, mod.d, 6, 2, M, M / 3, s));
+  };
+  double ms = time_ms(s, iters, fn);
+  // spot check (epilogue 0 and 1 only: plain value check)
+  out.pull();
+  double worst = 0;
+  if (epi == LL_EPI_BIAS) {
+    for (int t = 0; t < 64; ++t) {
+      int m = (int)(rnd() % M), n = (int)(rnd() % N);
+      if (t < 4) { m = M - 1 - t; n = N - 1 - t; }
+      double acc = bf2f(bias.h[n]);
+      for (int k = 0; k < K; ++k) acc += (double)bf2f(x.h[(size_t)m * K + k]) * bf2f(w.h[(size_t)n * K + k]);
+      double err = fabs(acc - bf2f(out.h[(size_t)m * N + n])) / (fabs(acc) * 0.0079 + 2e-3);
+      if (err > worst) worst = err;
+    }
+  }
+  printf("gemm %-10s M=%5d N=%5d K=%5d epi=%d : %8.1f us  %7.1f TFLOP/s   check(ulp-ish)=%.2f %s\n", name, M, N, K, epi,
+         ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst, worst > 1.0 ? "**FAIL**" : "");
+}
+
+static void bench_attn(const char* name, int Lq, int H, int Sk, int n0, int iters) {
+  Buf q((size_t)Lq * H * 128, 1.0f), k((size_t)Sk * H * 128, 1.0f), v((size_t)Sk * H * 128, 0.7f), o((size_t)Lq * H * 128, 0.f);
+  hipStream_t s = 0;
+  float scale = 1.0f / sqrtf(128.f);
+  auto fn = [&]() {
+    LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, Lq, H, H * 128, H * 128, H * 128, (long long)Sk * H * 128, 0, n0, 0, 0, scale, s));
+  };
+  double ms = time_ms(s, iters, fn);
+  o.pull();
+  double worst = 0;
+  for (int t = 0; t < 6; ++t) {
+    int qi = (t < 2) ? Lq - 1 - t : (int)(rnd() % Lq), hh = (int)(rnd() % H);
+    std::vector<double> sc(n0);
+    double mx = -1e300;
+    for (int j = 0; j < n0; ++j) {
+      double a = 0;
+      for (int d = 0; d < 128; ++d) a += (double)bf2f(q.h[((size_t)qi * H + hh) * 128 + d]) * bf2f(k.h[((size_t)j * H + hh) * 128 + d]);
+      sc[j] = a * scale;
+      if (sc[j] > mx) mx = sc[j];
+    }
+    double l = 0;
+    for (int j = 0; j < n0; ++j) { sc[j] = exp(sc[j] - mx); l += sc[j]; }
+    for (int d = 0; d < 128; d += (getenv("KBENCH_DEBUG") ? 1 : 17)) {
+      double a = 0;
+      for (int j = 0; j < n0; ++j) a += sc[j] * bf2f(v.h[((size_t)j * H + hh) * 128 + d]);
+      a /= l;
+      double got = bf2f(o.h[((size_t)qi * H + hh) * 128 + d]);
+      double err = fabs(a - got);
+      if (err > worst) worst = err;
+      if (getenv("KBENCH_DEBUG") && t < 3) printf("   q=%d d=%3d want %+.4f got %+.4f %s\n", qi, d, a, got, err > 1e-2 ? "<<<" : "");
+    }
+  }
+  printf("attn %-10s Lq=%5d H=%2d Lk=%5d      : %8.1f us  %7.1f TFLOP/s   max|err|=%.2e %s\n", name, Lq, H, n0, ms * 1e3,
+         4.0 * Lq * (double)n0 * 128 * H / (ms * 1e-3) / 1e12, worst, worst > 1e-2 ? "**FAIL**" : "");
+}
+
+int main(int argc, char** argv) {
+  const char* what = argc > 1 ? argv[1] : "all";
+  int iters = argc > 2 ? atoi(argv[2]) : 20;
+  bool all = !strcmp(what, "all");
+  if (all || !strcmp(what, "gemm")) {
+   for (int variant = 2; variant <= 3; ++variant) {
+    LL(ll_set_tuning("gemm_variant", variant));
+    printf("-- gemm_variant %d\n", variant);
+    bench_gemm("qkv", 4680, 4608, 1536, LL_EPI_BIAS, iters);
+    bench_gemm("o/q/co", 4680, 1536, 1536, LL_EPI_BIAS, iters);
+    bench_gemm("o+gate", 4680, 1536, 1536, LL_EPI_BIAS_GATE_RES, iters);
+    bench_gemm("ffn1", 4680, 8960, 1536, LL_EPI_BIAS_GELU, iters);
+    bench_gemm("ffn2", 4680, 1536, 8960, LL_EPI_BIAS_GATE_RES, iters);
+    bench_gemm("ffn2-plain", 4680, 1536, 8960, LL_EPI_BIAS, iters);
+    bench_gemm("recache-qkv", 18720, 4608, 1536, LL_EPI_BIAS, iters > 5 ? 5 : iters);
+    bench_gemm("sq4096", 4096, 4096, 4096, LL_EPI_BIAS, iters);
+    bench_gemm("edge", 300, 136, 128, LL_EPI_BIAS, 2);
+   }
+  }
+  if (all || !strcmp(what, "attn")) {
+   for (int variant = 0; variant <= 1; ++variant) {
+    LL(ll_set_tuning("attn_variant", variant));
+    printf("-- attn_variant %d\n", variant);
+    bench_attn("self", 4680, 12, 18720, 18720, iters);
+    bench_attn("self-b1", 4680, 12, 18720, 9360, iters);
+    bench_attn("cross", 4680, 12, 512, 512, iters);
+    bench_attn("ragged", 200, 2, 300, 157, 3);
+    bench_attn("tiny", 33, 1, 7, 7, 3);
+    bench_attn("onetile", 64, 1, 64, 64, 3);
+   }
+  }
+  return 0;
+}
