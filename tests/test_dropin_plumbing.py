@@ -1,0 +1,57 @@
+"""CPU checks of the drop-in plumbing that the reference's pipelines rely on: parameter names,
+module attributes, and the reference-format cache dicts whose end indices are int64[1] tensors."""
+from types import SimpleNamespace
+
+import torch
+
+from longlive_amd import synth
+from longlive_amd.model import CausalWanModelHIP, _kv_commit, _kv_state
+from longlive_amd.pipeline import CausalInferencePipeline
+from longlive_amd.wan_wrapper import WanDiffusionWrapper
+
+
+def test_state_dict_names_are_the_reference_names():
+    cfg = synth.toy_config()
+    m = CausalWanModelHIP(cfg, device="cpu")
+    want = synth.param_shapes(cfg)     # the same dict loads strictly into the reference's CausalWanModel (make_golden.py)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    sd = synth.synth_state_dict(cfg, seed=3)
+    m.load_state_dict(sd, strict=True)
+    # wrapper accepts the reference's "model."-prefixed checkpoint keys (inference.py:72-94)
+    w = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=3, sink_size=1, cfg=cfg, device="cpu",
+                            state_dict={"model." + k: v for k, v in sd.items()})
+    assert torch.equal(w.model.blocks[1].ffn[2].weight, sd["blocks.1.ffn.2.weight"])
+    assert set(k for k in w.state_dict()) == set("model." + k for k in sd)
+
+
+def test_max_attention_size_propagation_like_the_reference_pipeline():
+    cfg = synth.toy_config(local_attn_size=3, sink_size=1)
+    gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=3, sink_size=1, cfg=cfg, device="cpu")
+    holders = [n for n, mod in gen.model.named_modules() if hasattr(mod, "max_attention_size")]
+    assert holders == [""] + [f"blocks.{i}.self_attn" for i in range(cfg.num_layers)]   # root + self-attention only
+    args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=3, sink_size=1, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=1,
+                           context_noise=0)
+    P = CausalInferencePipeline(args, "cpu", generator=gen)
+    assert (P.num_transformer_blocks, P.frame_seq_length) == (cfg.num_layers, cfg.frame_seqlen)
+    P._set_all_modules_max_attention_size(3)
+    assert gen.model.max_attention_size == 3 * cfg.frame_seqlen
+    assert all(b.self_attn.max_attention_size == 3 * cfg.frame_seqlen for b in gen.model.blocks)
+    assert [round(float(t), 2) for t in P.denoising_step_list] == [1000.0, 937.5, 833.33, 625.0]
+    assert gen.model._prepare_blockwise_causal_attn_mask(device="cpu", num_frames=3) is None
+
+
+def test_reference_cache_dicts_with_tensor_indices():
+    """pipeline/causal_inference.py:271-277 allocates end indices as int64[1] tensors: they are read once, then only
+    written, and the python shadow stays authoritative."""
+    cache = {"k": torch.zeros(1, 8, 2, 128), "v": torch.zeros(1, 8, 2, 128),
+             "global_end_index": torch.tensor([5]), "local_end_index": torch.tensor([3])}
+    assert _kv_state(cache) == (5, 3)
+    _kv_commit(cache, 9, 7)
+    assert int(cache["global_end_index"]) == 9 and int(cache["local_end_index"]) == 7 and cache["_ll_idx"] == [9, 7]
+    cache["global_end_index"].fill_(123)          # a stale device value must not override the shadow
+    assert _kv_state(cache) == (9, 7)
+    ours = {"global_end_index": 0, "local_end_index": 0}
+    _kv_commit(ours, 4, 4)
+    assert ours["global_end_index"] == 4 and _kv_state(ours) == (4, 4)
