@@ -241,19 +241,25 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, r);
 }
 
-#ifdef LL_XHALF_SHFL
-__device__ __forceinline__ float xhalf_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
-__device__ __forceinline__ float xhalf_sum(float x) { return x + __shfl_xor(x, 32, 64); }
-#else
+// Cross-half (lane ^ 32) reductions on the VALU: v_permlane32_swap exchanges lanes 32-63 of its first operand with
+// lanes 0-31 of the second, so with both operands = x the results are [x_lo | x_lo] and [x_hi | x_hi].  The hazard
+// "VALU write -> v_permlane read" needs 2 wait states; the builtin form read stale registers here (wrong row sums), so
+// the instruction is issued from inline asm with the s_nop inside the statement.
+__device__ __forceinline__ void xhalf_swap(float x, float& lo, float& hi) {
+  lo = x;
+  hi = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+}
 __device__ __forceinline__ float xhalf_max(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+  float a, b;
+  xhalf_swap(x, a, b);
+  return fmaxf(a, b);
 }
 __device__ __forceinline__ float xhalf_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  float a, b;
+  xhalf_swap(x, a, b);
+  return a + b;
 }
-#endif
 
 #define PIPE_KSTAGES 2
 #define PIPE_VSTAGES 3
@@ -493,7 +499,7 @@ extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* 
   sg.nt0 = (sg.n0 + KT - 1) / KT;
   sg.nt = sg.nt0 + (sg.n1 + KT - 1) / KT;
   float c = scale * 1.4426950408889634f;
-  if (g_attn_variant == 1 && sg.n1 == 0)
+  if (g_attn_variant >= 1 && sg.n1 == 0)
     return flash_attn_pipe_launch(q, k, v, out, B, Lq, H, ldq, ldo, ldk, k_batch_stride, sg.s0, sg.n0, c, stream);
   constexpr int NW = 4;
   dim3 grid((Lq + NW * 32 - 1) / (NW * 32), H, B), block(NW * 64);

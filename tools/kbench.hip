@@ -174,6 +174,8 @@ int main(int argc, char** argv) {
     bench_attn("self-b1", 4680, 12, 18720, 9360, iters);
     bench_attn("cross", 4680, 12, 512, 512, iters);
     bench_attn("ragged", 200, 2, 300, 157, 3);
+    bench_attn("ragged-long", 700, 3, 1500, 1437, 3);
+    bench_attn("long-1tile+", 300, 2, 1100, 1025, 3);
     bench_attn("tiny", 33, 1, 7, 7, 3);
     bench_attn("onetile", 64, 1, 64, 64, 3);
    }
