@@ -60,9 +60,14 @@ class RefModel:
     """Functional CausalWanModel (wan/modules/causal_model.py:511-1068), KV-cache branch only."""
 
     def __init__(self, cfg: RefConfig, sd: Dict[str, Tensor], dtype=torch.bfloat16,
-                 frame_seqlen_for_max_attn: int = 1560):
+                 frame_seqlen_for_max_attn: int = 1560, lora: Optional[Dict[str, Tuple[Tensor, Tensor]]] = None,
+                 lora_scaling: float = 1.0):
         self.cfg = cfg
         self.dtype = dtype
+        # un-merged LoRA adapters {module name: (A [r,in], B [out,r])}: peft's published forward
+        #   y = base(x) + lora_B(lora_A(x)) * scaling   (what the reference runs at inference, inference.py:97-130)
+        self.lora = {k: (a.to(dtype), b.to(dtype)) for k, (a, b) in (lora or {}).items()}
+        self.lora_scaling = lora_scaling
         self.sd = {k: v.to(dtype) for k, v in sd.items()}
         self.freqs = R.make_freqs(cfg.dim // cfg.num_heads)
         # causal_model.py:82-88 hard-codes 1560 tokens/frame in max_attention_size; the pipelines
@@ -73,7 +78,11 @@ class RefModel:
 
     # -- helpers ----------------------------------------------------------------------------
     def lin(self, x: Tensor, name: str) -> Tensor:
-        return F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"))
+        y = F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"))
+        if name in self.lora:
+            a, b = self.lora[name]
+            y = y + F.linear(F.linear(x, a), b) * self.lora_scaling
+        return y
 
     # -- self attention (causal_model.py:97-370, KV branch :205-370) --------------------------
     def self_attn(self, x: Tensor, p: str, grid, kv_cache: dict, current_start: int,

@@ -186,3 +186,28 @@ def test_real_shape_forward_vs_reference():
     assert r < 3e-2 and cosine(flow.cpu(), rec["flow_steady"]) > 0.9995
     assert (kv[0]["global_end_index"], kv[0]["local_end_index"]) == tuple(rec["idx_steady"])
     assert rel_l2(kv[29]["k"][0, rec["slots_steady"]].cpu(), rec["k_l29_steady"]) < 5e-2
+
+
+def test_real_shape_interactive_recache_smoke():
+    """LongLive-1.3B shape through the interactive pipeline with one prompt switch (recache of 9 frames in ONE forward,
+    Lq = 14040): finite latents, end indices as the reference's state machine leaves them, recache touches all 30 caches."""
+    from longlive_amd.pipeline import InteractiveCausalInferencePipeline
+    cfg, gen = _real_model()
+    fs = cfg.frame_seqlen
+    prompts = {f"p{i}": {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + i, device=DEV)} for i in range(2)}
+    I = InteractiveCausalInferencePipeline(_pipe_args(False), DEV, generator=gen, text_encoder=lambda text_prompts: prompts[text_prompts[0]])
+    I.randn_like = TD.HashRandn(47)
+    T = 15
+    _, lat = I.inference(synth.synth_noise(cfg, T, seed=0, device=DEV), text_prompts_list=[["p0"], ["p1"]],
+                         switch_frame_indices=[7], return_latents=True, profile=True)
+    assert torch.isfinite(lat.float()).all()
+    assert 0.5 < float(lat.float().std()) < 2.0
+    assert (I.kv_cache1[0]["global_end_index"], I.kv_cache1[0]["local_end_index"]) == (T * fs, 12 * fs)
+    assert I.last_profile["switch_blocks"] == [3]                      # first block whose start (9) >= 7
+    assert all(c["is_init"] for c in I.crossattn_cache)
+    # different prompt after the switch => latents differ from a single-prompt run from the switch block on
+    from longlive_amd.pipeline import CausalInferencePipeline
+    P = CausalInferencePipeline(_pipe_args(True), DEV, generator=gen, text_encoder=lambda text_prompts: prompts[text_prompts[0]])
+    P.randn_like = TD.HashRandn(47)
+    _, lat1 = P.inference(synth.synth_noise(cfg, T, seed=0, device=DEV), ["p0"], return_latents=True)
+    assert torch.equal(lat[:, :9], lat1[:, :9]) and not torch.equal(lat[:, 9:], lat1[:, 9:])

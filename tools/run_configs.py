@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Runs BASELINE.json's long configurations on one MI355X with the pipelines' own profiler and prints one JSON object:
+  config 3: 60-s single-prompt generation (T = 240 latent frames, sliding KV cache + frame sink)
+  config 4: interactive multi-prompt stream (T = 240, 6 prompts, switches at 40,80,120,160,200, global_sink = false:
+            configs/longlive_interactive_inference.yaml:21-27) exercising KV-recache on every switch.
+Random-init LongLive-1.3B weights, synthetic prompt embeddings / noise (longlive_amd.synth)."""
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from longlive_amd import synth  # noqa: E402
+from longlive_amd.pipeline import CausalInferencePipeline, InteractiveCausalInferencePipeline  # noqa: E402
+from longlive_amd.wan_wrapper import WanDiffusionWrapper  # noqa: E402
+
+
+def args(gs):
+    return SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
+                           context_noise=0, global_sink=gs)
+
+
+def main():
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 240
+    dev = torch.device("cuda", 0)
+    cfg = synth.longlive_1_3b(local_attn_size=12, sink_size=3)
+    gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=dev,
+                              state_dict=synth.synth_state_dict(cfg, seed=0, device=dev))
+    prompts = {f"p{i}": {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + i, device=dev)} for i in range(6)}
+    enc = lambda text_prompts: prompts[text_prompts[0]]
+    noise = synth.synth_noise(cfg, T, seed=0, device=dev)
+    out = {"T_latent": T, "pixel_frames": 4 * T}
+
+    P = CausalInferencePipeline(args(True), dev, generator=gen, text_encoder=enc)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    _, lat = P.inference(noise, ["p0"], return_latents=True, profile=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    pr = P.last_profile
+    out["config3_single_prompt"] = {
+        "wall_s": dt, "fps_overall": 4 * T / dt, "steady_ms_per_latent_frame": pr["ms_per_latent_frame"],
+        "fps_steady": 4000.0 / pr["ms_per_latent_frame"], "block0_ms": pr["block_times_ms"][0],
+        "finite": bool(torch.isfinite(lat.float()).all()), "latent_std": float(lat.float().std()),
+        "end_indices": [P.kv_cache1[0]["global_end_index"], P.kv_cache1[0]["local_end_index"]]}
+
+    sw = [s for s in (40, 80, 120, 160, 200) if s < T]
+    I = InteractiveCausalInferencePipeline(args(False), dev, generator=gen, text_encoder=enc)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    _, lat = I.inference(noise, text_prompts_list=[[f"p{i}"] for i in range(len(sw) + 1)], switch_frame_indices=sw,
+                         return_latents=True, profile=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    pr = I.last_profile
+    out["config4_interactive"] = {
+        "wall_s": dt, "fps_overall": 4 * T / dt, "steady_ms_per_latent_frame": pr["ms_per_latent_frame"],
+        "switch_blocks": pr["switch_blocks"], "switch_block_ms": pr.get("switch_block_ms"),
+        "switch_latency_ms": pr.get("switch_latency_ms"), "finite": bool(torch.isfinite(lat.float()).all()),
+        "latent_std": float(lat.float().std()),
+        "end_indices": [I.kv_cache1[0]["global_end_index"], I.kv_cache1[0]["local_end_index"]]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
