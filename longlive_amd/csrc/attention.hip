@@ -269,14 +269,20 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
                                                                      const bf16* __restrict__ Vc, bf16* __restrict__ O,
                                                                      int Lq, int ldq, int ldo, int ldk,
                                                                      long long k_batch_stride, int kstart, int nkeys,
-                                                                     float c) {
+                                                                     float c, int nqt, int xcd_placement) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [K stage 0,1][V stage 0,1,2] x 16 KiB
   char* const ksm = smem;
   char* const vsm = smem + PIPE_KSTAGES * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  const int b = blockIdx.z;
+  // XCD-aware placement: workgroup ids that share an XCD (id % 8) get a contiguous, head-major range of (head, q-tile)
+  // pairs, so one head's K/V stream is pulled into ~2 of the 8 L2s instead of all 8 (PMC: 8 x 57.5 MB per launch before).
+  int nwg_ = gridDim.x, bid_ = blockIdx.x;
+  int qq_ = nwg_ >> 3, rr_ = nwg_ & 7, xcd_ = bid_ & 7;
+  int lid_ = xcd_placement ? (xcd_ < rr_ ? xcd_ * (qq_ + 1) : rr_ * (qq_ + 1) + (xcd_ - rr_) * qq_) + (bid_ >> 3) : bid_;
+  const int head = lid_ / nqt, qtile = lid_ % nqt;
+  const int q0 = qtile * (NW * 32) + wave * 32;
   const int nt = (nkeys + KT - 1) / KT;
   const int last_valid = nkeys - (nt - 1) * KT;
 
@@ -415,6 +421,17 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
       }
     rs = xhalf_sum(rs);
     l_run = l_run * alpha + rs;
+#ifdef LL_ATTN_SCHED
+    // pin the phase-A interleave: per MFMA one K-fragment read and a slice of the softmax VALU/transcendental work
+    // (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8, DS_READ 0x100, TRANS 0x400)
+#pragma unroll
+    for (int g_ = 0; g_ < 16; ++g_) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, LL_ATTN_SCHED, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+    }
+#endif
 
     if (__any(m_new != m_run)) {   // wave-uniform, exact: alpha == 1 in every lane otherwise
 #pragma unroll
@@ -445,6 +462,15 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
       vs2 = vs2 >= PIPE_VSTAGES ? vs2 - PIPE_VSTAGES : vs2;
       PIPE_STORE(t & 1, vs2);      // K(t+2) over K(t) (read an iteration ago), V(t+2) over V(t-1)
     }
+#ifdef LL_ATTN_SCHED_B
+    // phase-B interleave: per MFMA the two transposed V reads of the NEXT MFMA; staging writes spread behind them
+#pragma unroll
+    for (int g_ = 0; g_ < 16; ++g_) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+      __builtin_amdgcn_sched_group_barrier(0x002, LL_ATTN_SCHED_B, 1);
+    }
+#endif
     __syncthreads();
     s_cur[0] = s_nxt[0];
     s_cur[1] = s_nxt[1];
@@ -467,7 +493,9 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
   }
 }
 
-static int g_attn_variant = 1;   // 0: simple kernel, 1: software-pipelined kernel (single key range)
+static int g_attn_variant = 1;
+static int g_attn_xcd = 1;
+void ll_set_attn_xcd_internal(int v) { g_attn_xcd = v; }   // 0: simple kernel, 1: software-pipelined kernel (single key range)
 void ll_set_attn_variant_internal(int v) { g_attn_variant = v; }
 
 static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B,
@@ -480,9 +508,10 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
     (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  dim3 grid((Lq + NW * 32 - 1) / (NW * 32), H, B), block(NW * 64);
+  int nqt = (Lq + NW * 32 - 1) / (NW * 32);
+  dim3 grid(nqt * H, 1, B), block(NW * 64);
   hipLaunchKernelGGL(flash_attn_pipe_kernel<NW>, grid, block, lds, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
-                     (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, kstart, nkeys, c);
+                     (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
   return ll_check_launch("ll_flash_attn(pipe)");
 }
 

@@ -360,9 +360,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel_v3(const bf16* __rest
 // runtime tuning switches (A/B experiments from tools/kbench; defaults are the shipped configuration)
 static int g_gemm_variant = 0;
 void ll_set_attn_variant_internal(int v);
+void ll_set_attn_xcd_internal(int v);
 extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return LL_OK; }
   if (!strcmp(key, "attn_variant")) { ll_set_attn_variant_internal(value); return LL_OK; }
+  if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }
