@@ -168,9 +168,8 @@ int main(int argc, char** argv) {
   }
   if (all || !strcmp(what, "attn")) {
    for (int variant = 0; variant <= 1; ++variant) {
-    LL(ll_set_tuning("attn_variant", 1));
-    LL(ll_set_tuning("attn_xcd", variant));
-    printf("-- attn_variant 1, xcd placement %d\n", variant);
+    LL(ll_set_tuning("attn_variant", variant));
+    printf("-- attn_variant %d\n", variant);
     bench_attn("self", 4680, 12, 18720, 18720, iters);
     bench_attn("self-b1", 4680, 12, 18720, 9360, iters);
     bench_attn("cross", 4680, 12, 512, 512, iters);
