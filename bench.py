@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2, help="layers of one steady-state forward timed on the CPU")
+    ap.add_argument("--quant", choices=["none", "int8"], default="none",
+                    help="int8: W8A8 block linears (BASELINE config 5); the headline metric is the default bf16 path")
     return ap.parse_args()
 
 
@@ -107,6 +109,8 @@ def main():
     sd = synth.synth_state_dict(cfg, seed=0, device=dev)               # random-init weights of the 1.3B architecture
     gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=dev, state_dict=sd)
     del sd
+    if args.quant == "int8":
+        gen.model.set_quant("int8")
     pargs = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
                             denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
                             context_noise=0, global_sink=True)
@@ -146,7 +150,8 @@ def main():
         "metric": "generated frames/sec (832x480) LongLive-1.3B, frame-sink + short-window attention, 4 denoise steps + clean-context pass",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": (fps / BASELINE_FPS) if BASELINE_FPS else None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": (fps / BASELINE_FPS) if BASELINE_FPS else None,
+        "dtype": "bf16" if args.quant == "none" else "int8 (W8A8 block linears, bf16 attention/norms)", "data": "synthetic",
         "config": {"workload": "LongLive-1.3B 832x480 (latent 16x60x104), 3-frame AR blocks at steady state: "
                                "Lq=4680, Lk=18720 (sink 3 + window 12 frames), 5 DiT forwards/block, 30 layers, random-init weights",
                    "frames_per_step": 3 * PIXEL_FRAMES_PER_LATENT, "ms_per_latent_frame": 1e3 * elapsed / args.steps / 3,

@@ -57,6 +57,13 @@ int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf
 int ll_layernorm_affine(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int rows, int C,
                         float eps, ll_stream stream);
 
+/* int8 mode: the same two kernels emitting per-row symmetric int8 + scale (bit-identical to ll_quantize_rows applied to
+ * their bf16 output) so the following W8A8 GEMM reads its operand without an extra pass. */
+int ll_ln_modulate_q8(const ll_bf16* x, int8_t* q, float* qscale, const ll_bf16* e, const ll_bf16* mod, int nmod,
+                      int shift_idx, int scale_idx, int B, int L, int C, int F, float eps, ll_stream stream);
+int ll_layernorm_affine_q8(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, int8_t* q, float* qscale, int rows,
+                           int C, float eps, ll_stream stream);
+
 /* out = bf16(x * rsqrt(mean(x^2) + eps)) * w over the FULL width C (WanRMSNorm, wan/modules/model.py:70-86).
  * ldx / ldo = row strides in elements (lets the caller normalise a column slice of a fused projection). */
 int ll_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, int ldx, int ldo, float eps,
@@ -89,6 +96,17 @@ int ll_kv_roll(ll_bf16* cache_k, ll_bf16* cache_v, int B, int S, int C, int dst,
 int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
                  int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod, int nmod,
                  int gate_idx, int rows_per_batch, int frame_len, ll_stream stream);
+
+/* W8A8 variant of ll_gemm_bf16 for BASELINE config 5 ("INT8-quantized linear layers"; the reference ships no INT8 code,
+ * reports.md:24,39): out = epilogue(sx[m] * sw[n] * (xq[M,K] . wq[N,K]^T) + bias) with int8 operands, exact int32
+ * accumulation on v_mfma_i32_16x16x64_i8 and the same fused epilogues.  sx [M] / sw [N] fp32; K % 128 == 0. */
+int ll_gemm_w8a8(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias, ll_bf16* out,
+                 int M, int N, int K, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,
+                 int nmod, int gate_idx, int rows_per_batch, int frame_len, ll_stream stream);
+
+/* Symmetric per-row int8 quantisation: scale[r] = max|x[r,:]| / 127 (1 for an all-zero row), q = rint(x / scale).
+ * Per token for activations, per output channel for weights ([N,K] rows), x row stride ldx elements. */
+int ll_quantize_rows(const ll_bf16* x, int8_t* q, float* scale, int rows, int K, int ldx, ll_stream stream);
 
 /* Small-M linear (M <= 8): out = act_out(act_in(x) @ w^T + b); act: 0 none, 1 SiLU.  time_embedding /
  * time_projection (wan/modules/causal_model.py:605-608,976-979). */

@@ -20,10 +20,14 @@ SIGNATURES = {
     "ll_set_tuning": [C.c_char_p, _i],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "ll_ln_modulate_q8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "ll_layernorm_affine_q8": [_p, _p, _p, _p, _p, _i, _i, _f, _p],
     "ll_rmsnorm": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ll_qk_norm_rope_kv_store": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_kv_roll": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_gemm_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ll_quantize_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ll_linear_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p],
     "ll_patchify": [_p, _p, _i, _i, _i, _i, _i, _p],

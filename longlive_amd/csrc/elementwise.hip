@@ -51,6 +51,54 @@ __device__ __forceinline__ void layernorm_stats(const RowRegs& r, int C, int lan
   rstd = 1.0f / sqrtf(var + eps);
 }
 
+// Row output: bf16, or (int8 mode) symmetric per-row int8 + scale computed from the SAME bf16-rounded values the bf16
+// path would have stored, so fused and unfused quantisation are bit-identical (scale = max|y| / 127, q = rint(y / scale)).
+template <int NCH>
+__device__ __forceinline__ void emit_row(const RowRegs& y, int C, int lane, int row, bf16* __restrict__ out,
+                                         int8_t* __restrict__ q, float* __restrict__ qscale) {
+  if (q == nullptr) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = (lane + 64 * i) * 8;
+      if (c < C) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)y.v[i][j];
+        *reinterpret_cast<bf16x8*>(out + (size_t)row * C + c) = o;
+      }
+    }
+    return;
+  }
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    if ((lane + 64 * i) * 8 < C) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(y.v[i][j]));
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sc = mx > 0.f ? mx / 127.0f : 1.0f;
+  float inv = 1.0f / sc;
+  if (lane == 0) qscale[row] = sc;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      unsigned lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int a = __float2int_rn(y.v[i][j] * inv), b = __float2int_rn(y.v[i][4 + j] * inv);
+        a = a < -127 ? -127 : (a > 127 ? 127 : a);
+        b = b < -127 ? -127 : (b > 127 ? 127 : b);
+        lo |= (unsigned)(a & 0xFF) << (8 * j);
+        hi |= (unsigned)(b & 0xFF) << (8 * j);
+      }
+      *reinterpret_cast<uint2*>(q + (size_t)row * C + c) = make_uint2(lo, hi);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LN (no affine) + per-frame modulation.  Rounding points of the reference (bf16 tensors, causal_model.py:445):
 //   y = bf16(LN(x)); s1 = bf16(1 + bf16(mod_s + e_s)); out = bf16(bf16(y * s1) + bf16(mod_t + e_t))
@@ -58,7 +106,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
                                                           const bf16* __restrict__ e, const bf16* __restrict__ mod,
                                                           int nmod, int shift_idx, int scale_idx, int rows, int L,
-                                                          int C, int frame_len, int F, float eps) {
+                                                          int C, int frame_len, int F, float eps,
+                                                          int8_t* __restrict__ q, float* __restrict__ qscale) {
   int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -76,24 +125,24 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict
       bf16x8 et = *reinterpret_cast<const bf16x8*>(eb + (size_t)shift_idx * C + c);
       bf16x8 ms = *reinterpret_cast<const bf16x8*>(mod + (size_t)scale_idx * C + c);
       bf16x8 mt = *reinterpret_cast<const bf16x8*>(mod + (size_t)shift_idx * C + c);
-      bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float y = rbf((r.v[i][j] - mean) * rstd);
         float s1 = rbf(1.0f + rbf((float)ms[j] + (float)es[j]));
         float t = rbf((float)mt[j] + (float)et[j]);
-        o[j] = (bf16)(rbf(y * s1) + t);
+        r.v[i][j] = rbf(rbf(y * s1) + t);
       }
-      *reinterpret_cast<bf16x8*>(out + (size_t)row * C + c) = o;
     }
   }
+  emit_row<NCH>(r, C, lane, row, out, q, qscale);
 }
 
 // LN with affine (norm3): F.layer_norm computes (x-mean)*rstd*w + b in fp32 and rounds once.
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                                const bf16* __restrict__ bb, bf16* __restrict__ out,
-                                                               int rows, int C, float eps) {
+                                                               int rows, int C, float eps, int8_t* __restrict__ q,
+                                                               float* __restrict__ qscale) {
   int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -107,12 +156,11 @@ __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16* __res
     if (c < C) {
       bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
       bf16x8 bv = *reinterpret_cast<const bf16x8*>(bb + c);
-      bf16x8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16)((r.v[i][j] - mean) * rstd * (float)wv[j] + (float)bv[j]);
-      *reinterpret_cast<bf16x8*>(out + (size_t)row * C + c) = o;
+      for (int j = 0; j < 8; ++j) r.v[i][j] = rbf((r.v[i][j] - mean) * rstd * (float)wv[j] + (float)bv[j]);
     }
   }
+  emit_row<NCH>(r, C, lane, row, out, q, qscale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -345,8 +393,9 @@ __global__ __launch_bounds__(64) void sigma_lookup_kernel(const float* __restric
 
 static inline bool row_ok(int C) { return C > 0 && C <= 2048 && (C % 8) == 0; }
 
-extern "C" int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf16* mod, int nmod,
-                              int shift_idx, int scale_idx, int B, int L, int C, int F, float eps, ll_stream stream) {
+static int ln_modulate_launch(const ll_bf16* x, ll_bf16* out, int8_t* q, float* qscale, const ll_bf16* e,
+                              const ll_bf16* mod, int nmod, int shift_idx, int scale_idx, int B, int L, int C, int F,
+                              float eps, ll_stream stream) {
   LL_REQUIRE(row_ok(C), "ll_ln_modulate: C=%d must be a multiple of 8 and <= 2048", C);
   LL_REQUIRE(F > 0 && L % F == 0, "ll_ln_modulate: L=%d not divisible by F=%d", L, F);
   LL_REQUIRE(shift_idx >= 0 && shift_idx < nmod && scale_idx >= 0 && scale_idx < nmod, "ll_ln_modulate: bad mod index");
@@ -355,23 +404,46 @@ extern "C" int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, 
   dim3 grid((rows + 3) / 4);
 #define CALL(N)                                                                                                   \
   hipLaunchKernelGGL(ln_modulate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, \
-                     (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps)
+                     (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps, q, qscale)
   DISPATCH_NCH(C, CALL);
 #undef CALL
   return ll_check_launch("ll_ln_modulate");
 }
 
-extern "C" int ll_layernorm_affine(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int rows, int C,
-                                   float eps, ll_stream stream) {
+extern "C" int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf16* mod, int nmod,
+                              int shift_idx, int scale_idx, int B, int L, int C, int F, float eps, ll_stream stream) {
+  return ln_modulate_launch(x, out, nullptr, nullptr, e, mod, nmod, shift_idx, scale_idx, B, L, C, F, eps, stream);
+}
+
+extern "C" int ll_ln_modulate_q8(const ll_bf16* x, int8_t* q, float* qscale, const ll_bf16* e, const ll_bf16* mod,
+                                 int nmod, int shift_idx, int scale_idx, int B, int L, int C, int F, float eps,
+                                 ll_stream stream) {
+  LL_REQUIRE(q && qscale, "ll_ln_modulate_q8: q and qscale are required");
+  return ln_modulate_launch(x, nullptr, q, qscale, e, mod, nmod, shift_idx, scale_idx, B, L, C, F, eps, stream);
+}
+
+static int layernorm_affine_launch(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int8_t* q,
+                                   float* qscale, int rows, int C, float eps, ll_stream stream) {
   LL_REQUIRE(row_ok(C), "ll_layernorm_affine: C=%d must be a multiple of 8 and <= 2048", C);
   if (rows == 0) return LL_OK;
   dim3 grid((rows + 3) / 4);
 #define CALL(N)                                                                                              \
   hipLaunchKernelGGL(layernorm_affine_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x,   \
-                     (const bf16*)w, (const bf16*)b, (bf16*)out, rows, C, eps)
+                     (const bf16*)w, (const bf16*)b, (bf16*)out, rows, C, eps, q, qscale)
   DISPATCH_NCH(C, CALL);
 #undef CALL
   return ll_check_launch("ll_layernorm_affine");
+}
+
+extern "C" int ll_layernorm_affine(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int rows, int C,
+                                   float eps, ll_stream stream) {
+  return layernorm_affine_launch(x, w, b, out, nullptr, nullptr, rows, C, eps, stream);
+}
+
+extern "C" int ll_layernorm_affine_q8(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, int8_t* q, float* qscale,
+                                      int rows, int C, float eps, ll_stream stream) {
+  LL_REQUIRE(q && qscale, "ll_layernorm_affine_q8: q and qscale are required");
+  return layernorm_affine_launch(x, w, b, nullptr, q, qscale, rows, C, eps, stream);
 }
 
 extern "C" int ll_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, int ldx, int ldo,

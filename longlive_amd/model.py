@@ -120,6 +120,9 @@ class CausalWanModelHIP(nn.Module):
             b.self_attn.max_attention_size = self.max_attention_size
         self.num_frame_per_block = 1
         self.block_mask = None
+        # None: bf16 linears (the reference's precision).  "int8": W8A8 for the six per-token linears of every block
+        # (BASELINE config 5; per-token activation scales, per-output-channel weight scales, int32 accumulation).
+        self.quant: Optional[str] = None
         self._packed = None
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -150,13 +153,37 @@ class CausalWanModelHIP(nn.Module):
         P = []
         for blk in self.blocks:
             sa, ca = blk.self_attn, blk.cross_attn
-            P.append(dict(
+            d = dict(
                 wqkv=torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous(),
                 bqkv=torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous(),
                 mod=blk.modulation.detach().reshape(6, -1).contiguous(),
-            ))
+            )
+            if self.quant == "int8":
+                for name, w in (("qkv", d["wqkv"]), ("o", sa.o.weight), ("cq", ca.q.weight), ("co", ca.o.weight),
+                                ("f1", blk.ffn[0].weight), ("f2", blk.ffn[2].weight)):
+                    d["q_" + name], d["s_" + name] = ops.quantize_rows(w.detach().contiguous())
+            P.append(d)
         self._packed = P
+        self._packed_quant = self.quant
         return P
+
+    def set_quant(self, mode: Optional[str]):
+        """None (bf16) or "int8" (W8A8 block linears).  Weights are (re)quantised lazily at the next forward."""
+        if mode not in (None, "int8"):
+            raise ValueError(f"unknown quantisation mode {mode!r}")
+        if mode == "int8" and (self.cfg.dim % 128 or self.cfg.ffn_dim % 128):
+            raise ValueError("int8 linears need dim and ffn_dim to be multiples of 128")
+        self.quant = mode
+        self._packed = None
+        return self
+
+    def _lin(self, x, pk, key, w, b, epilogue=0, **kw):
+        """One block linear: bf16 MFMA GEMM, or W8A8 GEMM in int8 mode (same fused epilogues).  In int8 mode `x` is either
+        a bf16 tensor (quantised here, per token) or an already quantised (int8, scale) pair from a fused producer."""
+        if self.quant == "int8":
+            xq, sx = x if isinstance(x, tuple) else ops.quantize_rows(x)
+            return ops.gemm_w8a8(xq, sx, pk["q_" + key], pk["s_" + key], b, epilogue, **kw)
+        return ops.gemm(x, w, b, epilogue, **kw)
 
     def _rope_tables(self, hp: int, wp: int, device):
         """fp32 (cos, sin) tables from the reference's fp64 angles (model.py:29-36; causal_model.py:622-629):
@@ -242,8 +269,9 @@ class CausalWanModelHIP(nn.Module):
             pk, kvc, cac = P[i], kv_cache[i], crossattn_cache[i]
             sa, ca = blk.self_attn, blk.cross_attn
             # --- self attention (causal_model.py:444-456) ---
-            h1 = ops.ln_modulate(xs, e0, pk["mod"], 0, 1, F, c.eps)
-            qkv = ops.gemm(h1, pk["wqkv"], pk["bqkv"])
+            q8 = self.quant == "int8"
+            h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 0, 1, F, c.eps)
+            qkv = self._lin(h1, pk, "qkv", pk["wqkv"], pk["bqkv"])
             G, E = _kv_state(kvc)
             S = kvc["k"].shape[1]
             plan = plan_update(current_start, L, G, E, S, self.sink_size * fs, self.local_attn_size,
@@ -255,11 +283,11 @@ class CausalWanModelHIP(nn.Module):
                                       kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
                                       plan.roped_offset, plan.write_len, c.eps)
             att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
-            ops.gemm(att.view(B, L, C), sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
+            self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
                      mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
             # --- cross attention (causal_model.py:460; model.py:159-194) ---
-            xn = ops.layernorm_affine(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
-            qc = ops.rmsnorm(ops.gemm(xn, ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
+            xn = (ops.layernorm_affine_q8 if q8 else ops.layernorm_affine)(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
+            qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
             if not cac["is_init"]:
                 kc = ops.gemm(ctx, ca.k.weight, ca.k.bias)
                 if cac["k"].shape != (B, c.text_len, Hh, D) or not cac["k"].is_contiguous():
@@ -269,11 +297,11 @@ class CausalWanModelHIP(nn.Module):
                 ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
                 cac["is_init"] = True
             atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
-            ops.gemm(atc.view(B, L, C), ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
+            self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
             # --- FFN (causal_model.py:462-468) ---
-            h2 = ops.ln_modulate(xs, e0, pk["mod"], 3, 4, F, c.eps)
-            ff = ops.gemm(h2, blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
-            ops.gemm(ff, blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
+            h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 3, 4, F, c.eps)
+            ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
+            self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
                      mod=pk["mod"], gate_idx=5, rows_per_batch=L, frame_len=fs)
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):

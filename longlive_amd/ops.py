@@ -84,6 +84,32 @@ def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps:
     return out
 
 
+def ln_modulate_q8(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float):
+    """ln_modulate emitting (int8 [B,L,C], float32 scale [B*L]) for a following W8A8 GEMM."""
+    _chk(x, "x"); _chk(e, "e"); _chk(mod, "mod")
+    B, L, Cc = x.shape
+    nmod = mod.shape[-2]
+    assert e.shape == (B, num_frames, nmod, Cc) and mod.numel() == nmod * Cc
+    q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    sc = torch.empty(B * L, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_ln_modulate_q8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), e.data_ptr(), mod.data_ptr(), nmod,
+                                     shift_idx, scale_idx, B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate_q8")
+    return q, sc
+
+
+def layernorm_affine_q8(x, w, b, eps: float):
+    _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_layernorm_affine_q8(x.data_ptr(), w.data_ptr(), b.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, Cc,
+                                          eps, _stream()), "ll_layernorm_affine_q8")
+    return q, sc
+
+
 def layernorm_affine(x, w, b, eps: float, out=None):
     _chk(x, "x"); _chk(w, "w"); _chk(b, "b")
     Cc = x.shape[-1]
@@ -175,6 +201,54 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
     _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                 _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
                "ll_gemm_bf16")
+    if timer is not None:
+        timer.end("gemm", t0, 2.0 * M * N * K)
+    return out
+
+
+def quantize_rows(x, q=None, scale=None):
+    """Per-row symmetric int8 quantisation of a [..., K] bf16 tensor -> (int8 [..., K], float32 scale [rows])."""
+    _chk(x, "x")
+    K = x.shape[-1]
+    rows = x.numel() // K
+    if q is None:
+        q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    if scale is None:
+        scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _chk(q, "q", torch.int8); _chk(scale, "scale", torch.float32)
+    assert q.numel() == x.numel() and scale.numel() == rows
+    lib = _lib.load()
+    _lib.check(lib.ll_quantize_rows(x.data_ptr(), q.data_ptr(), scale.data_ptr(), rows, K, K, _stream()), "ll_quantize_rows")
+    return q, scale
+
+
+def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
+              rows_per_batch: int = 0, frame_len: int = 0):
+    """out[M,N] = epilogue(sx[m] sw[n] (xq[M,K] @ wq[N,K]^T) + bias): int8 operands, int32 accumulation, bf16 out."""
+    _chk(xq, "xq", torch.int8); _chk(wq, "wq", torch.int8); _chk(sx, "sx", torch.float32); _chk(sw, "sw", torch.float32)
+    _chk(bias, "bias")
+    K = xq.shape[-1]
+    M = xq.numel() // K
+    N = wq.shape[0]
+    assert wq.shape == (N, K) and bias.numel() == N and sx.numel() == M and sw.numel() == N
+    if out is None:
+        out = torch.empty(*xq.shape[:-1], N, dtype=bf16, device=xq.device)
+    _chk(out, "out")
+    assert out.numel() == M * N
+    nmod = 0
+    if epilogue in (EPI_BIAS_GATE_RES, EPI_BIAS_RES):
+        _chk(res, "res")
+        assert res.numel() == M * N
+    if epilogue == EPI_BIAS_GATE_RES:
+        _chk(e, "e"); _chk(mod, "mod")
+        nmod = mod.shape[-2]
+        assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
+        assert e.numel() == (M // frame_len) * nmod * N
+    lib = _lib.load()
+    t0 = timer.begin("gemm") if timer is not None else None
+    _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+                                out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
+                                rows_per_batch, frame_len, _stream()), "ll_gemm_w8a8")
     if timer is not None:
         timer.end("gemm", t0, 2.0 * M * N * K)
     return out

@@ -211,3 +211,30 @@ def test_real_shape_interactive_recache_smoke():
     P.randn_like = TD.HashRandn(47)
     _, lat1 = P.inference(synth.synth_noise(cfg, T, seed=0, device=DEV), ["p0"], return_latents=True)
     assert torch.equal(lat[:, :9], lat1[:, :9]) and not torch.equal(lat[:, 9:], lat1[:, 9:])
+
+
+def test_int8_linears_vs_bf16_path():
+    """BASELINE config 5: W8A8 block linears.  The reference has no INT8 implementation (reports.md:24,39), so the
+    contract is closeness to the bf16 path: per forward rel-L2 <= 6e-2 and cosine >= 0.998 on the real 30-layer shape
+    (per-token / per-channel symmetric int8 carries ~1% relative error per linear)."""
+    rec = load_golden("real_fwd.pt")
+    cfg, gen = _real_model()
+    fs, S = cfg.frame_seqlen, 12 * cfg.frame_seqlen
+    prompt = synth.synth_prompt_embeds(cfg, seed=1, device=DEV)
+    noise = synth.synth_noise(cfg, 3, seed=0, device=DEV)
+    outs = {}
+    for mode in (None, "int8"):
+        gen.model.set_quant(mode)
+        kv = [dict(k=torch.zeros(1, S, 12, 128, dtype=bf, device=DEV), v=torch.zeros(1, S, 12, 128, dtype=bf, device=DEV),
+                   global_end_index=0, local_end_index=0) for _ in range(30)]
+        ca = [dict(k=torch.zeros(1, 512, 12, 128, dtype=bf, device=DEV), v=torch.zeros(1, 512, 12, 128, dtype=bf, device=DEV),
+                   is_init=False) for _ in range(30)]
+        t = torch.full((1, 3), 1000.0, device=DEV)
+        flow, _ = gen(noise, {"prompt_embeds": prompt}, t, kv_cache=kv, crossattn_cache=ca, current_start=0)
+        outs[mode] = flow.cpu()
+    gen.model.set_quant(None)
+    r = rel_l2(outs["int8"], outs[None])
+    print(f"int8 vs bf16 (HIP): relL2 {r:.2e} cos {cosine(outs['int8'], outs[None]):.6f}; "
+          f"int8 vs reference bf16: {rel_l2(outs['int8'], rec['flow_block0']):.2e}")
+    assert r < 6e-2 and cosine(outs["int8"], outs[None]) > 0.998
+    assert rel_l2(outs["int8"], rec["flow_block0"]) < 7e-2

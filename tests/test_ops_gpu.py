@@ -229,3 +229,48 @@ def test_patchify_unpatchify_x0_add_noise(ops):
     want = sch.add_noise(x0_ref.flatten(0, 1), nz, tt)
     got = ps.add_noise(x0.flatten(0, 1), nz.to(DEV), tt.to(DEV))
     assert torch.equal(got.cpu(), want), "add_noise must be bit-exact"
+
+
+def _dequant_check(q, sc, ref_bf16, what):
+    """q * scale must reproduce the bf16 tensor to within half a quantisation step per row."""
+    deq = q.cpu().float() * sc.cpu().view(-1, 1)
+    ref = ref_bf16.float().reshape(deq.shape)
+    step = ref.abs().amax(dim=1, keepdim=True) / 127.0
+    assert ((deq - ref).abs() <= 0.5 * step + 1e-6).all(), what
+    assert torch.allclose(sc.cpu(), (ref.abs().amax(dim=1) / 127.0).clamp_min(0) + (ref.abs().amax(dim=1) == 0).float(), rtol=1e-6), what
+
+
+def test_int8_quantize_and_w8a8_gemm(ops):
+    M, N, K = 333, 264, 384
+    x, w, b = hn("qx", (M, K), 1.5), hn("qw", (N, K), 0.05), hn("qb", (N,), 0.1)
+    x[17] = 0                                                     # an all-zero row keeps scale 1
+    xq, sx = ops.quantize_rows(x.to(DEV))
+    wq, sw = ops.quantize_rows(w.to(DEV))
+    _dequant_check(xq, sx, x, "activation quantisation")
+    _dequant_check(wq, sw, w, "weight quantisation")
+    got = ops.gemm_w8a8(xq, sx, wq, sw, b.to(DEV)).cpu()
+    # exact integer reference of the same quantised operands
+    acc = xq.cpu().to(torch.int64) @ wq.cpu().to(torch.int64).t()
+    want = (acc.double() * (sx.cpu().double().view(-1, 1) * sw.cpu().double().view(1, -1)) + b.double()).float().to(bf)
+    assert_bf16_close(got, want, 1, 0.97, "w8a8 gemm vs exact integer reference")
+    # and close to the unquantised product
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel_l2(got, ref) < 2e-2
+    # fused epilogues share code with the bf16 kernel: check the residual one
+    res = hn("qres", (M, N))
+    got2 = ops.gemm_w8a8(xq, sx, wq, sw, b.to(DEV), ops.EPI_BIAS_RES, res=res.to(DEV))
+    assert_bf16_close(got2, res + want, 1, 0.97, "w8a8 gemm + residual")
+
+
+def test_fused_ln_quantisation_is_bit_identical_to_unfused(ops):
+    C, F, fs, B = 1536, 3, 40, 1
+    x = hn("x", (B, F * fs, C), 1.7, 0.3).to(DEV)
+    e = hn("e", (B, F, 6, C), 0.5).to(DEV)
+    mod = hn("mod", (6, C), 1 / math.sqrt(C)).to(DEV)
+    q1, s1 = ops.ln_modulate_q8(x, e, mod, 0, 1, F, 1e-6)
+    q2, s2 = ops.quantize_rows(ops.ln_modulate(x, e, mod, 0, 1, F, 1e-6))
+    assert torch.equal(q1, q2) and torch.equal(s1, s2)
+    w, b = hn("w", (C,), 0.1, 1.0).to(DEV), hn("b", (C,), 0.1).to(DEV)
+    q1, s1 = ops.layernorm_affine_q8(x, w, b, 1e-6)
+    q2, s2 = ops.quantize_rows(ops.layernorm_affine(x, w, b, 1e-6))
+    assert torch.equal(q1, q2) and torch.equal(s1, s2)

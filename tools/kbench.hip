@@ -111,6 +111,43 @@ static void bench_gemm(const char* name, int M, int N, int K, int epi, int iters
          ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, worst, worst > 1.0 ? "**FAIL**" : "");
 }
 
+static void bench_gemm_i8(const char* name, int M, int N, int K, int iters) {
+  Buf x((size_t)M * K, 1.0f), w((size_t)N * K, 1.0f / sqrtf((float)K)), bias(N, 0.1f), out((size_t)M * N, 0.f);
+  int8_t *xq, *wq; float *sx, *sw;
+  CK(hipMalloc(&xq, (size_t)M * K)); CK(hipMalloc(&wq, (size_t)N * K)); CK(hipMalloc(&sx, M * 4)); CK(hipMalloc(&sw, N * 4));
+  hipStream_t s = 0;
+  LL(ll_quantize_rows(x.d, xq, sx, M, K, K, s));
+  LL(ll_quantize_rows(w.d, wq, sw, N, K, K, s));
+  double qms = time_ms(s, iters, [&]() { LL(ll_quantize_rows(x.d, xq, sx, M, K, K, s)); });
+  auto fn = [&]() { LL(ll_gemm_w8a8(xq, sx, wq, sw, bias.d, out.d, M, N, K, N, LL_EPI_BIAS, nullptr, nullptr, nullptr, 0, 0, 0, 0, s)); };
+  double ms = time_ms(s, iters, fn);
+  out.pull();
+  std::vector<int8_t> hx((size_t)M * K), hw((size_t)N * K);
+  std::vector<float> hsx(M), hsw(N);
+  CK(hipMemcpy(hx.data(), xq, hx.size(), hipMemcpyDeviceToHost)); CK(hipMemcpy(hw.data(), wq, hw.size(), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hsx.data(), sx, M * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hsw.data(), sw, N * 4, hipMemcpyDeviceToHost));
+  double worst = 0, worst_vs_bf16 = 0;
+  for (int t = 0; t < 48; ++t) {
+    int m = (int)(rnd() % M), n = (int)(rnd() % N);
+    if (t < 4) { m = M - 1 - t; n = N - 1 - t; }
+    long long acc = 0;
+    double ref = bf2f(bias.h[n]);
+    for (int k = 0; k < K; ++k) {
+      acc += (long long)hx[(size_t)m * K + k] * hw[(size_t)n * K + k];
+      ref += (double)bf2f(x.h[(size_t)m * K + k]) * bf2f(w.h[(size_t)n * K + k]);
+    }
+    double want = (double)acc * ((double)hsx[m] * hsw[n]) + bf2f(bias.h[n]);
+    double got = bf2f(out.h[(size_t)m * N + n]);
+    double err = fabs(want - got) / (fabs(want) * 0.0079 + 2e-3);
+    if (err > worst) worst = err;
+    double e2 = fabs(ref - got);
+    if (e2 > worst_vs_bf16) worst_vs_bf16 = e2;
+  }
+  printf("w8a8 %-10s M=%5d N=%5d K=%5d       : %8.1f us  %7.1f TOP/s  (quantize x: %.1f us)  exact-int check=%.2f %s  max|err vs fp|=%.3f\n",
+         name, M, N, K, ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12, qms * 1e3, worst, worst > 1.0 ? "**FAIL**" : "", worst_vs_bf16);
+  hipFree(xq); hipFree(wq); hipFree(sx); hipFree(sw);
+}
+
 static void bench_attn(const char* name, int Lq, int H, int Sk, int n0, int iters) {
   Buf q((size_t)Lq * H * 128, 1.0f), k((size_t)Sk * H * 128, 1.0f), v((size_t)Sk * H * 128, 0.7f), o((size_t)Lq * H * 128, 0.f);
   hipStream_t s = 0;
@@ -165,6 +202,12 @@ int main(int argc, char** argv) {
     bench_gemm("sq4096", 4096, 4096, 4096, LL_EPI_BIAS, iters);
     bench_gemm("edge", 300, 136, 128, LL_EPI_BIAS, 2);
    }
+   LL(ll_set_tuning("gemm_variant", 0));
+   bench_gemm_i8("qkv", 4680, 4608, 1536, iters);
+   bench_gemm_i8("o/q/co", 4680, 1536, 1536, iters);
+   bench_gemm_i8("ffn1", 4680, 8960, 1536, iters);
+   bench_gemm_i8("ffn2", 4680, 1536, 8960, iters);
+   bench_gemm_i8("edge", 300, 136, 256, 2);
   }
   if (all || !strcmp(what, "attn")) {
    for (int variant = 0; variant <= 1; ++variant) {
