@@ -204,3 +204,81 @@ def synth_prompt_embeds(cfg: WanConfig, seed: int = 1, batch: int = 1, valid_tok
         valid_tokens = min(40, cfg.text_len)
     x[:, valid_tokens:] = 0
     return x.to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Wan VAE decoder (wan/modules/vae.py:369-472, 612-624: dim 96, z_dim 16, dim_mult [1,2,4,4], 2 res blocks,
+# temporal upsample [True, True, False])
+@dataclass
+class VaeConfig:
+    dim: int = 96
+    z_dim: int = 16
+    dim_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    temporal_upsample: Tuple[bool, ...] = (True, True, False)
+
+
+def vae_decoder_layout(cfg: VaeConfig):
+    """The decoder's layer list in execution order: ('res', name, cin, cout) | ('attn', name, c) |
+    ('up3d' | 'up2d', name, c).  Mirrors Decoder3d.__init__ (vae.py:386-421)."""
+    dims = [cfg.dim * u for u in [cfg.dim_mult[-1]] + list(cfg.dim_mult[::-1])]
+    layers = [("res", "decoder.middle.0", dims[0], dims[0]), ("attn", "decoder.middle.1", dims[0]),
+              ("res", "decoder.middle.2", dims[0], dims[0])]
+    idx = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(cfg.num_res_blocks + 1):
+            layers.append(("res", f"decoder.upsamples.{idx}", cin, cout))
+            idx += 1
+            cin = cout
+        if i != len(cfg.dim_mult) - 1:
+            layers.append(("up3d" if cfg.temporal_upsample[i] else "up2d", f"decoder.upsamples.{idx}", cout))
+            idx += 1
+    return dims, layers
+
+
+def vae_decoder_param_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
+    dims, layers = vae_decoder_layout(cfg)
+    sh: Dict[str, Tuple[int, ...]] = {"conv2.weight": (cfg.z_dim, cfg.z_dim, 1, 1, 1), "conv2.bias": (cfg.z_dim,),
+                                      "decoder.conv1.weight": (dims[0], cfg.z_dim, 3, 3, 3), "decoder.conv1.bias": (dims[0],)}
+    for L in layers:
+        kind, name = L[0], L[1]
+        if kind == "res":
+            cin, cout = L[2], L[3]
+            sh[name + ".residual.0.gamma"] = (cin, 1, 1, 1)
+            sh[name + ".residual.2.weight"] = (cout, cin, 3, 3, 3); sh[name + ".residual.2.bias"] = (cout,)
+            sh[name + ".residual.3.gamma"] = (cout, 1, 1, 1)
+            sh[name + ".residual.6.weight"] = (cout, cout, 3, 3, 3); sh[name + ".residual.6.bias"] = (cout,)
+            if cin != cout:
+                sh[name + ".shortcut.weight"] = (cout, cin, 1, 1, 1); sh[name + ".shortcut.bias"] = (cout,)
+        elif kind == "attn":
+            c = L[2]
+            sh[name + ".norm.gamma"] = (c, 1, 1)
+            sh[name + ".to_qkv.weight"] = (3 * c, c, 1, 1); sh[name + ".to_qkv.bias"] = (3 * c,)
+            sh[name + ".proj.weight"] = (c, c, 1, 1); sh[name + ".proj.bias"] = (c,)
+        else:
+            c = L[2]
+            sh[name + ".resample.1.weight"] = (c // 2, c, 3, 3); sh[name + ".resample.1.bias"] = (c // 2,)
+            if kind == "up3d":
+                sh[name + ".time_conv.weight"] = (2 * c, c, 3, 1, 1); sh[name + ".time_conv.bias"] = (2 * c,)
+    c_out = dims[-1]
+    sh["decoder.head.0.gamma"] = (c_out, 1, 1, 1)
+    sh["decoder.head.2.weight"] = (3, c_out, 3, 3, 3); sh["decoder.head.2.bias"] = (3,)
+    return sh
+
+
+def synth_vae_state_dict(cfg: VaeConfig, seed: int = 0, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Random-init decoder weights (conv weights U(+-sqrt(3/fan_in)) so activations keep unit scale, gammas 1 + N(0,.1),
+    biases N(0,.02); proj.weight non-zero, unlike the reference's zero init vae.py:237, so the attention block matters)."""
+    sd = {}
+    for name, shape in vae_decoder_param_shapes(cfg).items():
+        if name.endswith("gamma"):
+            w = 1.0 + 0.1 * hash_normal(seed, name, shape, device)
+        elif name.endswith(".bias"):
+            w = 0.02 * hash_normal(seed, name, shape, device)
+        else:
+            fan_in = int(math.prod(shape[1:]))
+            w = (hash_uniform(seed, name, shape, device) * 2.0 - 1.0) * math.sqrt(3.0 / fan_in)
+        sd[name] = w.to(dtype)
+    return sd

@@ -420,5 +420,43 @@ def gen_pipe_calls(ns):
     _save("pipe_calls.pt", rec)
 
 
+# --------------------------------------------------------------------------------------------
+def gen_vae(ns):
+    """Reference WanVAE_ decoder (wan/modules/vae.py) through the reference WanVAEWrapper.decode_to_pixel code path, with
+    synthetic weights: full decode of 5 latent frames at 8x12 latents (64x96 pixels, 17 frames), and the streaming
+    (use_cache) variant fed in two pieces."""
+    import importlib
+    vae = importlib.import_module("wan.modules.vae")
+    vcfg = synth.VaeConfig()
+    sd = synth.synth_vae_state_dict(vcfg, seed=5)
+    model = vae.WanVAE_(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                        temperal_downsample=[False, True, True], dropout=0.0)
+    missing, unexpected = model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith(("encoder.", "conv1.")) for k in missing), (missing[:4], unexpected[:4])
+    model = model.to(torch.bfloat16).eval()
+    W = ns.wan_wrapper.WanVAEWrapper
+    wr = W.__new__(W)
+    nn.Module.__init__(wr)
+    wr.mean = torch.tensor(W_MEAN, dtype=torch.float32)
+    wr.std = torch.tensor(W_STD, dtype=torch.float32)
+    wr.model = model
+    lat = synth.hash_normal(55, "vae.latent", (1, 5, 16, 8, 12)).to(torch.bfloat16)
+    t0 = time.time()
+    full = wr.decode_to_pixel(lat, use_cache=False)
+    print(f"vae decode 5 frames @64x96: {time.time() - t0:.1f}s", tuple(full.shape))
+    model.clear_cache()
+    a = wr.decode_to_pixel(lat[:, :2], use_cache=True)
+    b = wr.decode_to_pixel(lat[:, 2:], use_cache=True)
+    model.clear_cache()
+    _save("vae_decode.pt", dict(full=full.to(torch.bfloat16), full_f32_sample=full[0, :, :, ::7, ::11].clone(),
+                                stream_a=a.to(torch.bfloat16), stream_b=b.to(torch.bfloat16)))
+
+
+W_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,
+          -0.1922, -0.9497, 0.2503, -0.2921]
+W_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382,
+         1.1253, 2.8251, 1.9160]
+
+
 if __name__ == "__main__":
     main(sys.argv[1:])
