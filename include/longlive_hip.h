@@ -146,6 +146,37 @@ int ll_add_noise(const ll_bf16* x0, const ll_bf16* noise, const float* sigma, ll
 int ll_sigma_lookup(const float* t, const float* timesteps, const float* sigmas, float* out, int n, int n_table,
                     ll_stream stream);
 
+/* ---- VAE decoder (wan/modules/vae.py, utils/wan_wrapper.py:83-116) ------------------- */
+
+/* CausalConv3d 3x3x3 / (3,1,1) / 1x1x1 and Conv2d 3x3 / 1x1 (wan/modules/vae.py:17-36; the Upsample + Conv2d pair of
+ * Resample, vae.py:74-84, with upsample=1) as one implicit GEMM on channels-last activations:
+ *   out[(t,ho,wo), co] = bias[co] (+ res[(t,ho,wo), co]) + sum x[t+kt-(KT-1), (ho+kh-p)>>up, (wo+kw-p)>>up, ci] * w[co, (kt,kh,kw), ci]
+ * x [T,H,W,Cin]; xcache [2,H,W,Cin] = frames t-2, t-1 of the stream (the reference's feat_cache, vae.py:29-34; zeros
+ * before the first frame); zero16 = 16 zero bytes on the device (spatial padding rows); w [Cout, Kpad] bf16 with
+ * k = ((kt*KH + kh)*KH + kw)*Cin + ci, zero padded to Kpad = ceil(KT*KH*KH*Cin / 64) * 64; out/res rows of ldo
+ * elements, output spatial size (H<<up, W<<up). */
+int ll_conv_cl(const ll_bf16* x, const ll_bf16* xcache, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias,
+               const ll_bf16* res, ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH,
+               int upsample, int ldo, ll_stream stream);
+
+/* RMS_norm over channels (+ SiLU) (wan/modules/vae.py:39-55,193-197) on channels-last rows with the reference's bf16
+ * rounding points: n = bf16(||x||); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = silu(y) if do_silu. */
+int ll_rms_silu_cl(const ll_bf16* x, const ll_bf16* gamma, ll_bf16* out, long long pixels, int C, int do_silu,
+                   ll_stream stream);
+
+/* p[:, :N] = softmax(scale * s[:, :N]) along rows of ld elements, p[:, N:ld] = 0 (the decoder's single-head attention,
+ * F.scaled_dot_product_attention at vae.py:249-254, as GEMM + softmax + GEMM). */
+int ll_softmax_rows(const ll_bf16* s, ll_bf16* p, int rows, int N, int ld, float scale, ll_stream stream);
+
+/* Latent un-scaling z / (1/std) + mean in bf16 (utils/wan_wrapper.py:99-110, wan/modules/vae.py:548-550) fused with the
+ * layout change [T, C, h, w] -> channels-last [T, h, w, C]. */
+int ll_vae_unscale_cl(const ll_bf16* z, const ll_bf16* mean, const ll_bf16* inv_std, ll_bf16* out, int T, int C, int h,
+                      int w, ll_stream stream);
+
+/* Decoder output: channels-last bf16 [T,H,W,ldc] (first 3 channels) -> fp32 [T,3,H,W] clamped to [-1,1]
+ * (wan/modules/vae.py decode's clamp_ + utils/wan_wrapper.py:112-116). */
+int ll_cl_to_tchw_clamp(const ll_bf16* x, float* out, int T, int H, int W, int ldc, ll_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,330 @@
+// Wan VAE decoder kernels: causal 3-D / 2-D convolution as an implicit GEMM on the MFMA
+// GEMM structure of gemm.hip, plus the decoder's row kernels.  Activations are CHANNELS-LAST bf16 [T, H, W, C].
+//
+// Convolution (CausalConv3d 3x3x3 / (3,1,1) / 1x1x1 and Conv2d 3x3 after a nearest x2 upsample, wan/modules/vae.py:17-36,
+// 74-84):   out[(t,ho,wo), co] = bias[co] + sum_{tap,ci} in[t + kt - (KT-1), (ho + kh - p) >> up, (wo + kw - p) >> up, ci] * w[co, tap, ci]
+//   = a GEMM with M = T*Ho*Wo output pixels, N = Cout, K = taps*Cin ordered (tap, ci).  In channels-last layout every
+//   16-byte chunk of a K-row is 8 consecutive channels of ONE shifted input pixel, and the LDS-DMA source address is per
+//   lane -- so the A tile is gathered straight into the GEMM's swizzled LDS image: no im2col buffer, padding = a pointer to
+//   a zero row, the two frames of temporal context = a pointer into the layer's cache, the nearest-neighbour upsample =
+//   a shift of the source coordinates.  Weights are re-ordered once at load to [Cout, Kpad] (Kpad = K rounded up to 64).
+// Tile: 256 pixels x 32*NT channels, 8 waves (4 x 2), 3-stage LDS ring (same as gemm v2); NT = 3 for Cout = 96 / 192.
+#include "gemm_common.h"
+
+#define CV_BM 256
+#define CV_STAGE ((CV_BM + 128) * ROWB)   // 48 KiB
+
+struct ConvGeo {
+  const char* x;        // current chunk [T, H, W, Cin]
+  const char* xc;       // temporal cache [2, H, W, Cin]: frames t-2, t-1 of the stream (zeros before the first frame)
+  const char* zero;     // >= 16 zero bytes
+  int T, H, W, Cin, Ho, Wo, KT, KH, up, cpt, nchunks;
+  unsigned inv_cpt;     // ceil(65536 / cpt): g / cpt == (g * inv_cpt) >> 16 for g < 4096
+};
+
+__device__ __forceinline__ void stage_conv_rows(const ConvGeo& g, int kstep, char* lds, int wave, int lane,
+                                                const int (&rt)[4], const int (&rh)[4], const int (&rw)[4]) {
+  const int pad = g.KH >> 1;
+  const size_t frame_bytes = (size_t)g.H * g.W * g.Cin * 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int inst = wave * 4 + i;
+    int r = inst * 8 + (lane >> 3);
+    int gch = kstep * 8 + ((lane & 7) ^ (r & 7));          // global 16-byte chunk of the K-row that belongs here
+    const char* src = g.zero;
+    if (gch < g.nchunks) {
+      int tap = (int)(((unsigned)gch * g.inv_cpt) >> 16);
+      int ci8 = gch - tap * g.cpt;
+      int kt, kh, kw;
+      if (g.KH == 3) {
+        kt = tap / 9;
+        int rem = tap - kt * 9;
+        kh = rem / 3;
+        kw = rem - kh * 3;
+      } else {
+        kt = tap; kh = 0; kw = 0;
+      }
+      int ti = rt[i] + kt - (g.KT - 1);
+      int hy = rh[i] + kh - pad, wx = rw[i] + kw - pad;
+      bool ok = hy >= 0 && hy < g.Ho && wx >= 0 && wx < g.Wo;
+      if (g.up) { hy >>= 1; wx >>= 1; }
+      const char* base = ti >= 0 ? g.x + (size_t)ti * frame_bytes : g.xc + (size_t)(ti + 2) * frame_bytes;
+      if (ok) src = base + ((size_t)(hy * g.W + wx) * g.Cin + ci8 * 8) * 2;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + inst * 1024), 16, 0, 0);
+  }
+}
+
+template <int EPI, int NT>
+__global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* __restrict__ Wt, bf16* __restrict__ Y,
+                                                         int M, int N, int nk, size_t wrow_bytes, int ldo, int ntm,
+                                                         int ntn, EpiArgs ea) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (lid / ntn) * CV_BM, n0 = (lid % ntn) * (32 * NT);
+
+  // output-pixel coordinates of the 4 A-rows this lane gathers
+  int rt[4], rh[4], rw[4];
+  const int hw = g.Ho * g.Wo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + (wave * 4 + i) * 8 + (lane >> 3);
+    m = m < M ? m : M - 1;
+    rt[i] = m / hw;
+    int rem = m - rt[i] * hw;
+    rh[i] = rem / g.Wo;
+    rw[i] = rem - rh[i] * g.Wo;
+  }
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int kt, int slot) {
+    char* base = smem + slot * CV_STAGE;
+    stage_conv_rows(g, kt, base, wave, lane, rt, rh, rw);
+    stage_rows(Wt, wrow_bytes, n0, N, kt * ROWB, base + CV_BM * ROWB, wave * 2, 2, lane);
+  };
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+
+  const int fr = lane & 15, fg = lane >> 4;
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      int s2 = slot + 2;
+      s2 = s2 >= 3 ? s2 - 3 : s2;
+      stage(kt + 2, s2);
+    }
+    const char* xs = smem + slot * CV_STAGE;
+    const char* ws = xs + CV_BM * ROWB;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[NT], xf[4];
+      int ch = ks * 4 + fg;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        int rwi = wn * (16 * NT) + t * 16 + fr;
+        wf[t] = *reinterpret_cast<const bf16x8*>(ws + rwi * ROWB + ((ch ^ (rwi & 7)) << 4));
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int rx = wm * 64 + t * 16 + fr;
+        xf[t] = *reinterpret_cast<const bf16x8*>(xs + rx * ROWB + ((ch ^ (rx & 7)) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  gemm_epilogue<EPI, false, NT, 4>(acc, Y, M, N, ldo, m0 + wm * 64, n0 + wn * (16 * NT), fr, fg, ea);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RMS_norm (+ SiLU) over channels, channels-last rows of C in {96, 192, 384} (wan/modules/vae.py:39-55, 193-197):
+//   n = bf16(||x||_2); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = bf16(silu(y))
+// (the reference's bf16 rounding points).  G lanes per pixel (16 / 32 / 64), 8 channels per lane.
+template <int G>
+__global__ __launch_bounds__(256) void rms_silu_cl_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
+                                                          bf16* __restrict__ out, long long pixels, int C, float sqrt_c,
+                                                          int do_silu) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (G - 1);
+  long long pix = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + (lane / G);
+  if (pix >= pixels) return;
+  const int c = sub * 8;
+  float v[8];
+  float ss = 0.f;
+  if (c < C) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(x + pix * C + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = (float)t[j]; ss += v[j] * v[j]; }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
+  if (c < C) {
+    bf16x8 gv = *reinterpret_cast<const bf16x8*>(gamma + c);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = rbf(rbf(rbf(v[j] / n) * sqrt_c) * (float)gv[j]);
+      o[j] = (bf16)(do_silu ? silu(y) : y);
+    }
+    *reinterpret_cast<bf16x8*>(out + pix * C + c) = o;
+  }
+}
+
+// Row softmax for the decoder's single-head attention (vae.py:249-254): p = softmax(scale * s) over N columns, bf16 out.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16* __restrict__ s, bf16* __restrict__ p, int rows, int N,
+                                                           int ld, float scale_log2e) {
+  int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16* sr = s + (size_t)row * ld;
+  float mx = -INFINITY;
+  for (int k = lane * 8; k < N; k += 512) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(sr + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, k + j < N ? (float)v[j] : -INFINITY);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float mc = mx * scale_log2e, sum = 0.f;
+  for (int k = lane * 8; k < N; k += 512) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(sr + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      sum += k + j < N ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[j], scale_log2e, -mc)) : 0.f;
+  }
+  sum = wave_sum(sum);
+  float inv = 1.0f / sum;
+  bf16* pr = p + (size_t)row * ld;
+  for (int k = lane * 8; k < ld; k += 512) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(sr + k);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)      // padding columns come out as zeros (the P.V contraction runs over ld)
+      o[j] = (bf16)(k + j < N ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[j], scale_log2e, -mc)) * inv : 0.f);
+    *reinterpret_cast<bf16x8*>(pr + k) = o;
+  }
+}
+
+// WanVAEWrapper.decode_to_pixel's un-scaling (utils/wan_wrapper.py:99-110 -> vae.py:548-550: z / (1/std) + mean in bf16)
+// fused with the layout change: latent [T, C, h, w] -> channels-last [T, h, w, C].
+__global__ __launch_bounds__(256) void vae_unscale_cl_kernel(const bf16* __restrict__ z, const bf16* __restrict__ mean,
+                                                             const bf16* __restrict__ inv_std, bf16* __restrict__ out, int C,
+                                                             long long hw, long long total) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // index into out
+  if (i >= total) return;
+  int c = (int)(i % C);
+  long long px = i / C, t = px / hw, p = px - t * hw;
+  float v = (float)z[(t * C + c) * hw + p];
+  out[i] = (bf16)(rbf(v / (float)inv_std[c]) + (float)mean[c]);
+}
+
+// Final layout change + clamp (utils/wan_wrapper.py:112-116): channels-last bf16 [T, H, W, ldc] (first 3 channels) ->
+// fp32 [T, 3, H, W] clamped to [-1, 1].
+__global__ __launch_bounds__(256) void cl_to_tchw_clamp_kernel(const bf16* __restrict__ x, float* __restrict__ out,
+                                                               long long pixels_per_frame, long long total, int ldc) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  long long t = i / pixels_per_frame, p = i - t * pixels_per_frame;
+  const bf16* px = x + i * ldc;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float v = (float)px[ch];
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    out[(t * 3 + ch) * pixels_per_frame + p] = v;
+  }
+}
+
+// ===============================================================================================================
+extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* xcache, const ll_bf16* zero16, const ll_bf16* w,
+                          const ll_bf16* bias, const ll_bf16* res, ll_bf16* out, int T, int H, int W, int Cin, int Cout,
+                          int Kpad, int KT, int KH, int upsample, int ldo, ll_stream stream) {
+  LL_REQUIRE(Cin > 0 && Cin % 8 == 0, "ll_conv_cl: Cin=%d must be a multiple of 8", Cin);
+  LL_REQUIRE(Cout > 0 && Cout % 8 == 0, "ll_conv_cl: Cout=%d must be a multiple of 8 (pad the weights)", Cout);
+  LL_REQUIRE((KT == 1 || KT == 3) && (KH == 1 || KH == 3), "ll_conv_cl: taps must be 1 or 3 (got %d x %d x %d)", KT, KH, KH);
+  LL_REQUIRE(upsample == 0 || upsample == 1, "ll_conv_cl: upsample must be 0 or 1");
+  LL_REQUIRE(KT == 1 || xcache != nullptr, "ll_conv_cl: a temporal convolution needs its 2-frame cache");
+  LL_REQUIRE(zero16 && bias, "ll_conv_cl: zero row and bias are required");
+  const int taps = KT * KH * KH;
+  const int nchunks = taps * (Cin / 8);
+  LL_REQUIRE(Kpad % 64 == 0 && Kpad >= nchunks * 8 && Kpad < nchunks * 8 + 64, "ll_conv_cl: Kpad=%d does not match taps*Cin=%d", Kpad, nchunks * 8);
+  LL_REQUIRE(nchunks < 4096, "ll_conv_cl: K too large for the chunk decoder");
+  LL_REQUIRE(ldo >= Cout && ldo % 4 == 0, "ll_conv_cl: ldo=%d must be >= Cout and a multiple of 4", ldo);
+  const int Ho = upsample ? 2 * H : H, Wo = upsample ? 2 * W : W;
+  const long long Mll = (long long)T * Ho * Wo;
+  LL_REQUIRE(Mll > 0 && Mll < (1ll << 31), "ll_conv_cl: too many output pixels");
+  const int M = (int)Mll;
+  ConvGeo g;
+  g.x = (const char*)x; g.xc = (const char*)(xcache ? xcache : zero16); g.zero = (const char*)zero16;
+  g.T = T; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.KT = KT; g.KH = KH; g.up = upsample;
+  g.cpt = Cin / 8; g.nchunks = nchunks; g.inv_cpt = (65536u + g.cpt - 1) / g.cpt;
+  EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  const int nk = Kpad / 64;
+  const bool nt3 = (Cout % 96 == 0) && (Cout % 128 != 0), nt1 = Cout <= 32;
+  const int bn = nt1 ? 32 : nt3 ? 96 : 128;
+  int ntm = (M + CV_BM - 1) / CV_BM, ntn = (Cout + bn - 1) / bn;
+  dim3 grid(ntm * ntn), block(512);
+  size_t lds = 3 * CV_STAGE;
+  hipStream_t s = (hipStream_t)stream;
+#define CV_LAUNCH(E, NTV)                                                                                              \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      (void)hipFuncSetAttribute((const void*)conv_cl_kernel<E, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((conv_cl_kernel<E, NTV>), grid, block, lds, s, g, (const char*)w, (bf16*)out, M, Cout, nk,       \
+                       (size_t)Kpad * 2, ldo, ntm, ntn, ea);                                                           \
+  } while (0)
+  if (res) {
+    if (nt1) CV_LAUNCH(LL_EPI_BIAS_RES, 1); else if (nt3) CV_LAUNCH(LL_EPI_BIAS_RES, 3); else CV_LAUNCH(LL_EPI_BIAS_RES, 4);
+  } else {
+    if (nt1) CV_LAUNCH(LL_EPI_BIAS, 1); else if (nt3) CV_LAUNCH(LL_EPI_BIAS, 3); else CV_LAUNCH(LL_EPI_BIAS, 4);
+  }
+#undef CV_LAUNCH
+  return ll_check_launch("ll_conv_cl");
+}
+
+extern "C" int ll_rms_silu_cl(const ll_bf16* x, const ll_bf16* gamma, ll_bf16* out, long long pixels, int C, int do_silu,
+                              ll_stream stream) {
+  LL_REQUIRE(C > 0 && C % 8 == 0 && C <= 512, "ll_rms_silu_cl: C=%d must be a multiple of 8 and <= 512", C);
+  if (pixels == 0) return LL_OK;
+  float sc = sqrtf((float)C);
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 128) {
+    long long per_block = 4 * 4;
+    hipLaunchKernelGGL(rms_silu_cl_kernel<16>, dim3((unsigned)((pixels + per_block - 1) / per_block)), dim3(256), 0, s,
+                       (const bf16*)x, (const bf16*)gamma, (bf16*)out, pixels, C, sc, do_silu);
+  } else if (C <= 256) {
+    long long per_block = 4 * 2;
+    hipLaunchKernelGGL(rms_silu_cl_kernel<32>, dim3((unsigned)((pixels + per_block - 1) / per_block)), dim3(256), 0, s,
+                       (const bf16*)x, (const bf16*)gamma, (bf16*)out, pixels, C, sc, do_silu);
+  } else {
+    long long per_block = 4;
+    hipLaunchKernelGGL(rms_silu_cl_kernel<64>, dim3((unsigned)((pixels + per_block - 1) / per_block)), dim3(256), 0, s,
+                       (const bf16*)x, (const bf16*)gamma, (bf16*)out, pixels, C, sc, do_silu);
+  }
+  return ll_check_launch("ll_rms_silu_cl");
+}
+
+extern "C" int ll_softmax_rows(const ll_bf16* s, ll_bf16* p, int rows, int N, int ld, float scale, ll_stream stream) {
+  LL_REQUIRE(N > 0 && ld >= N && ld % 8 == 0, "ll_softmax_rows: need 0 < N=%d <= ld=%d and ld a multiple of 8", N, ld);
+  if (rows == 0) return LL_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)s, (bf16*)p,
+                     rows, N, ld, scale * 1.4426950408889634f);
+  return ll_check_launch("ll_softmax_rows");
+}
+
+extern "C" int ll_vae_unscale_cl(const ll_bf16* z, const ll_bf16* mean, const ll_bf16* inv_std, ll_bf16* out, int T, int C,
+                                 int h, int w, ll_stream stream) {
+  long long hw = (long long)h * w, total = hw * T * C;
+  if (total == 0) return LL_OK;
+  hipLaunchKernelGGL(vae_unscale_cl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)z, (const bf16*)mean, (const bf16*)inv_std, (bf16*)out, C, hw, total);
+  return ll_check_launch("ll_vae_unscale_cl");
+}
+
+extern "C" int ll_cl_to_tchw_clamp(const ll_bf16* x, float* out, int T, int H, int W, int ldc, ll_stream stream) {
+  LL_REQUIRE(ldc >= 3, "ll_cl_to_tchw_clamp: needs >= 3 channels per pixel");
+  long long ppf = (long long)H * W, total = ppf * T;
+  if (total == 0) return LL_OK;
+  hipLaunchKernelGGL(cl_to_tchw_clamp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, out, ppf, total, ldc);
+  return ll_check_launch("ll_cl_to_tchw_clamp");
+}

@@ -356,3 +356,104 @@ def sigma_lookup(t, timesteps, sigmas):
     _lib.check(lib.ll_sigma_lookup(t.data_ptr(), timesteps.data_ptr(), sigmas.data_ptr(), out.data_ptr(), t.numel(),
                                    timesteps.numel(), _stream()), "ll_sigma_lookup")
     return out
+
+
+# ---- VAE decoder (channels-last) -------------------------------------------------------------------------------------
+_zero16 = {}
+
+
+def zero_row(device) -> torch.Tensor:
+    """64 zero bytes on `device`: the source of every padding chunk of the implicit-GEMM convolution."""
+    key = str(device)
+    if key not in _zero16:
+        _zero16[key] = torch.zeros(32, dtype=bf16, device=device)
+    return _zero16[key]
+
+
+def pack_conv_weight(w: torch.Tensor, bias: torch.Tensor):
+    """Reference conv weight [Cout, Cin, (kt,) kh, kw] -> the kernel's [Cout8, Kpad] bf16 with k = (tap, ci), rows padded
+    to a multiple of 8 output channels and K to a multiple of 64 (zeros), plus the padded bias.  One-time, at load."""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    cout, cin, kt, kh, kw = w.shape
+    assert kh == kw
+    k = kt * kh * kw * cin
+    kpad = (k + 63) // 64 * 64
+    cout8 = (cout + 7) // 8 * 8
+    packed = torch.zeros(cout8, kpad, dtype=bf16, device=w.device)
+    packed[:cout, :k] = w.permute(0, 2, 3, 4, 1).reshape(cout, k).to(bf16)
+    b = torch.zeros(cout8, dtype=bf16, device=w.device)
+    b[:cout] = bias.to(bf16)
+    return packed.contiguous(), b, (cin, cout8, kpad, kt, kh)
+
+
+def conv_cl(x, cache, packed, bias, geo, upsample: bool = False, res=None, out=None):
+    """x [T,H,W,Cin] channels-last; cache [2,H,W,Cin] or None (no temporal taps); packed/bias/geo from
+    pack_conv_weight.  Returns [T, H<<up, W<<up, Cout8]."""
+    cin, cout, kpad, kt, kh = geo
+    _chk(x, "x"); _chk(packed, "w"); _chk(bias, "bias")
+    T, H, W, C = x.shape
+    assert C == cin, f"conv_cl: input has {C} channels, weights expect {cin}"
+    assert packed.shape == (cout, kpad) and bias.numel() == cout
+    if kt > 1:
+        assert cache is not None and cache.shape == (2, H, W, cin), "conv_cl: temporal conv needs a [2,H,W,Cin] cache"
+        _chk(cache, "cache")
+    Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
+    if out is None:
+        out = torch.empty(T, Ho, Wo, cout, dtype=bf16, device=x.device)
+    assert out.shape == (T, Ho, Wo, cout) and out.is_contiguous()
+    if res is not None:
+        _chk(res, "res")
+        assert res.shape == out.shape
+    lib = _lib.load()
+    _lib.check(lib.ll_conv_cl(x.data_ptr(), _ptr(cache if kt > 1 else None), zero_row(x.device).data_ptr(), packed.data_ptr(),
+                              bias.data_ptr(), _ptr(res), out.data_ptr(), T, H, W, cin, cout, kpad, kt, kh,
+                              1 if upsample else 0, cout, _stream()), "ll_conv_cl")
+    return out
+
+
+def rms_silu_cl(x, gamma, silu: bool = True, out=None):
+    _chk(x, "x"); _chk(gamma, "gamma")
+    C = x.shape[-1]
+    assert gamma.numel() == C
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.ll_rms_silu_cl(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // C, C, 1 if silu else 0,
+                                  _stream()), "ll_rms_silu_cl")
+    return out
+
+
+def softmax_rows(s, scale: float, n_valid: Optional[int] = None, out=None):
+    """softmax(scale * s[:, :n_valid]) along the last dim; columns >= n_valid come out as zeros."""
+    _chk(s, "s")
+    ld = s.shape[-1]
+    N = ld if n_valid is None else n_valid
+    if out is None:
+        out = torch.empty_like(s)
+    lib = _lib.load()
+    _lib.check(lib.ll_softmax_rows(s.data_ptr(), out.data_ptr(), s.numel() // ld, N, ld, float(scale), _stream()),
+               "ll_softmax_rows")
+    return out
+
+
+def vae_unscale_cl(z, mean, inv_std):
+    """z [T, C, h, w] bf16 -> bf16(bf16(z / inv_std) + mean) as channels-last [T, h, w, C]."""
+    _chk(z, "z"); _chk(mean, "mean"); _chk(inv_std, "inv_std")
+    T, C, h, w = z.shape
+    assert mean.numel() == C and inv_std.numel() == C
+    out = torch.empty(T, h, w, C, dtype=bf16, device=z.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_vae_unscale_cl(z.data_ptr(), mean.data_ptr(), inv_std.data_ptr(), out.data_ptr(), T, C, h, w, _stream()),
+               "ll_vae_unscale_cl")
+    return out
+
+
+def cl_to_tchw_clamp(x):
+    """[T,H,W,C>=3] bf16 channels-last -> fp32 [T,3,H,W] clamped to [-1,1]."""
+    _chk(x, "x")
+    T, H, W, C = x.shape
+    out = torch.empty(T, 3, H, W, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_cl_to_tchw_clamp(x.data_ptr(), out.data_ptr(), T, H, W, C, _stream()), "ll_cl_to_tchw_clamp")
+    return out
