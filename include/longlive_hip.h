@@ -151,13 +151,14 @@ int ll_sigma_lookup(const float* t, const float* timesteps, const float* sigmas,
 /* CausalConv3d 3x3x3 / (3,1,1) / 1x1x1 and Conv2d 3x3 / 1x1 (wan/modules/vae.py:17-36; the Upsample + Conv2d pair of
  * Resample, vae.py:74-84, with upsample=1) as one implicit GEMM on channels-last activations:
  *   out[(t,ho,wo), co] = bias[co] (+ res[(t,ho,wo), co]) + sum x[t+kt-(KT-1), (ho+kh-p)>>up, (wo+kw-p)>>up, ci] * w[co, (kt,kh,kw), ci]
- * x [T,H,W,Cin]; xcache [2,H,W,Cin] = frames t-2, t-1 of the stream (the reference's feat_cache, vae.py:29-34; zeros
- * before the first frame); zero16 = 16 zero bytes on the device (spatial padding rows); w [Cout, Kpad] bf16 with
- * k = ((kt*KH + kh)*KH + kw)*Cin + ci, zero padded to Kpad = ceil(KT*KH*KH*Cin / 64) * 64; out/res rows of ldo
- * elements, output spatial size (H<<up, W<<up). */
-int ll_conv_cl(const ll_bf16* x, const ll_bf16* xcache, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias,
-               const ll_bf16* res, ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH,
-               int upsample, int ldo, ll_stream stream);
+ * x points at the first of T new frames [T,H,W,Cin]; when KT == 3 the two frames BEFORE it in memory (x - 2*H*W*Cin
+ * elements) must hold the previous two input frames of the stream -- the reference's feat_cache (vae.py:29-34) -- or
+ * zeros at the start of a stream.  zero16 = 16 zero bytes on the device (source of spatial / K padding);
+ * w [Cout, Kpad] bf16 with k = ((kt*KH + kh)*KH + kw)*Cin + ci, zero padded to Kpad = ceil(KT*KH*KH*Cin / 64) * 64;
+ * out/res rows of ldo elements, output spatial size (H<<up, W<<up). */
+int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
+               ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample, int ldo,
+               ll_stream stream);
 
 /* RMS_norm over channels (+ SiLU) (wan/modules/vae.py:39-55,193-197) on channels-last rows with the reference's bf16
  * rounding points: n = bf16(||x||); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = silu(y) if do_silu. */

@@ -15,47 +15,134 @@
 #define CV_STAGE ((CV_BM + 128) * ROWB)   // 48 KiB
 
 struct ConvGeo {
-  const char* x;        // current chunk [T, H, W, Cin]
-  const char* xc;       // temporal cache [2, H, W, Cin]: frames t-2, t-1 of the stream (zeros before the first frame)
+  const char* x;        // first NEW frame of [2 + T, H, W, Cin] when KT == 3 (two history frames precede it), else [T, H, W, Cin]
   const char* zero;     // >= 16 zero bytes
-  int T, H, W, Cin, Ho, Wo, KT, KH, up, cpt, nchunks;
+  int T, H, W, Cin, Ho, Wo, KT, KH, up, cpt, nchunks, taps;
   unsigned inv_cpt;     // ceil(65536 / cpt): g / cpt == (g * inv_cpt) >> 16 for g < 4096
 };
 
-__device__ __forceinline__ void stage_conv_rows(const ConvGeo& g, int kstep, char* lds, int wave, int lane,
-                                                const int (&rt)[4], const int (&rh)[4], const int (&rw)[4]) {
-  const int pad = g.KH >> 1;
-  const size_t frame_bytes = (size_t)g.H * g.W * g.Cin * 2;
+// A-tile staging.  LDS row r of the tile holds K-chunks 8s..8s+7 of output pixel r, chunk g at position (g & 7) ^ (r & 7)
+// (the GEMM's XOR swizzle); every lane DMA-copies one 16-byte chunk per instruction and (r & 7) == (lane >> 3) & 7 for all
+// of a lane's rows, so a lane always handles chunk column c = (lane & 7) ^ ((lane >> 3) & 7) of K-step s.
+//
+// MODE 1 / 2 (Cin >= 64, i.e. >= 8 chunks per tap): a K-step touches at most two taps, A = floor(8s / cpt) for chunk
+// columns < split and A + 1 for the rest.  Both taps are decoded on the SCALAR unit (kt, kh, kw, byte offset); a lane picks
+// one with a compare, adds it to its rows' precomputed base pointers and tests one precomputed validity bit per row:
+// ~35 VALU per K-step per wave instead of ~170 with per-lane div/mod and bounds checks -- the VALU pipe, shared by the 4
+// waves of a SIMD, was what bounded the first version of this kernel (profiles/r01_vae_kernels.md).
+// MODE 2 adds the nearest x2 upsample: source row (ho + kh - 1) >> 1 = base + ((kh + parity) >> 1).
+// MODE 0: generic per-lane decode for Cin < 64 (conv2, decoder.conv1: 16 input channels, < 0.1 % of the FLOPs).
+template <int MODE>
+struct ConvRows {
+  const char* ptr[4];   // MODE 1/2: address of the (kt, kh, kw) = (0, 0, 0) tap of each row's pixel, channel 0
+  unsigned mask[4];     // bit kh*KH + kw: tap inside the image; MODE 2: bits 16 / 17 = parity of (ho - 1) / (wo - 1)
+  int rt[4], rh[4], rw[4];   // MODE 0 only
+};
+
+template <int MODE>
+__device__ __forceinline__ void conv_rows_init(ConvRows<MODE>& R, const ConvGeo& g, int m0, int M, int wave, int lane) {
+  const int hw = g.Ho * g.Wo, pad = g.KH >> 1;
+  const long long fb = (long long)g.H * g.W * g.Cin * 2;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int inst = wave * 4 + i;
-    int r = inst * 8 + (lane >> 3);
-    int gch = kstep * 8 + ((lane & 7) ^ (r & 7));          // global 16-byte chunk of the K-row that belongs here
-    const char* src = g.zero;
-    if (gch < g.nchunks) {
-      int tap = (int)(((unsigned)gch * g.inv_cpt) >> 16);
-      int ci8 = gch - tap * g.cpt;
-      int kt, kh, kw;
-      if (g.KH == 3) {
-        kt = tap / 9;
-        int rem = tap - kt * 9;
-        kh = rem / 3;
-        kw = rem - kh * 3;
-      } else {
-        kt = tap; kh = 0; kw = 0;
+    int m = m0 + (wave * 4 + i) * 8 + (lane >> 3);
+    m = m < M ? m : M - 1;
+    int t = m / hw;
+    int rem = m - t * hw;
+    int h = rem / g.Wo;
+    int w = rem - h * g.Wo;
+    R.rt[i] = t; R.rh[i] = h; R.rw[i] = w;
+    unsigned mk = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int hy = h + kh - pad, wx = w + kw - pad;
+        bool ok = kh < g.KH && kw < g.KH && hy >= 0 && hy < g.Ho && wx >= 0 && wx < g.Wo;
+        mk |= ok ? 1u << (kh * g.KH + kw) : 0u;
       }
-      int ti = rt[i] + kt - (g.KT - 1);
-      int hy = rh[i] + kh - pad, wx = rw[i] + kw - pad;
-      bool ok = hy >= 0 && hy < g.Ho && wx >= 0 && wx < g.Wo;
-      if (g.up) { hy >>= 1; wx >>= 1; }
-      const char* base = ti >= 0 ? g.x + (size_t)ti * frame_bytes : g.xc + (size_t)(ti + 2) * frame_bytes;
-      if (ok) src = base + ((size_t)(hy * g.W + wx) * g.Cin + ci8 * 8) * 2;
+    if (MODE == 2) {
+      int a = h - 1, b = w - 1;
+      mk |= (unsigned)(a & 1) << 16 | (unsigned)(b & 1) << 17;
+      R.ptr[i] = g.x + (long long)t * fb + ((long long)(a >> 1) * g.W + (b >> 1)) * g.Cin * 2;
+    } else {
+      R.ptr[i] = g.x + (long long)(t - (g.KT - 1)) * fb + ((long long)(h - pad) * g.W + (w - pad)) * g.Cin * 2;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + inst * 1024), 16, 0, 0);
+    R.mask[i] = mk;
   }
 }
 
-template <int EPI, int NT>
+struct TapDec { int idx, off, kh, kw; };
+__device__ __forceinline__ TapDec decode_tap(const ConvGeo& g, int tap, int fb32) {   // uniform: runs on the scalar unit
+  TapDec d;
+  int kt = g.KH == 3 ? (tap * 57) >> 9 : tap;            // tap / 9 for tap < 27
+  int rem = g.KH == 3 ? tap - 9 * kt : 0;
+  d.kh = (rem * 11) >> 5;                                  // rem / 3 for rem < 9
+  d.kw = rem - 3 * d.kh;
+  bool live = tap < g.taps;
+  d.idx = live ? rem : 31;                                 // bit 31 of a row mask is always 0: K padding reads the zero row
+  d.off = live ? kt * fb32 + (d.kh * g.W + d.kw) * g.Cin * 2 : 0;
+  return d;
+}
+
+template <int MODE>
+__device__ __forceinline__ void stage_conv_rows(const ConvRows<MODE>& R, const ConvGeo& g, int kstep, char* lds, int wave,
+                                                int lane) {
+  const int c = (lane & 7) ^ ((lane >> 3) & 7);
+  if (MODE == 0) {
+    const int pad = g.KH >> 1;
+    const long long fb = (long long)g.H * g.W * g.Cin * 2;
+    int gch = kstep * 8 + c;
+    int tap = (int)(((unsigned)gch * g.inv_cpt) >> 16);
+    int ci8 = gch - tap * g.cpt;
+    int kt = g.KH == 3 ? tap / 9 : tap;
+    int rem = g.KH == 3 ? tap - kt * 9 : 0;
+    int kh = rem / 3, kw = rem - kh * 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int inst = wave * 4 + i;
+      int ti = R.rt[i] + kt - (g.KT - 1);
+      int hy = R.rh[i] + kh - pad, wx = R.rw[i] + kw - pad;
+      bool ok = gch < g.nchunks && hy >= 0 && hy < g.Ho && wx >= 0 && wx < g.Wo;
+      if (g.up) { hy >>= 1; wx >>= 1; }
+      const char* src = g.x + (long long)ti * fb + ((long long)(hy * g.W + wx) * g.Cin + ci8 * 8) * 2;
+      src = ok ? src : g.zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + inst * 1024), 16, 0, 0);
+    }
+  } else {
+    const int fb32 = g.H * g.W * g.Cin * 2;
+    int g0 = kstep * 8;
+    int tapA = (int)(((unsigned)g0 * g.inv_cpt) >> 16);
+    int ciA = g0 - tapA * g.cpt;
+    int split = g.cpt - ciA;                               // chunk columns >= split belong to tap A + 1 (cpt >= 8)
+    TapDec A = decode_tap(g, tapA, fb32), B = decode_tap(g, tapA + 1, fb32);
+    bool inB = c >= split;
+    int ci8 = inB ? c - split : ciA + c;
+    int idx = inB ? B.idx : A.idx;
+    if (MODE == 1) {
+      unsigned off = (unsigned)((inB ? B.off : A.off) + ci8 * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int inst = wave * 4 + i;
+        const char* src = ((R.mask[i] >> idx) & 1u) ? R.ptr[i] + off : g.zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + inst * 1024), 16, 0, 0);
+      }
+    } else {
+      int kh = inB ? B.kh : A.kh, kw = inB ? B.kw : A.kw;
+      const int c2 = g.Cin * 2, wc2 = g.W * c2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int inst = wave * 4 + i;
+        int dh = (kh + (int)((R.mask[i] >> 16) & 1u)) >> 1, dw = (kw + (int)((R.mask[i] >> 17) & 1u)) >> 1;
+        unsigned off = (unsigned)(dh * wc2 + dw * c2 + ci8 * 16);
+        const char* src = ((R.mask[i] >> idx) & 1u) ? R.ptr[i] + off : g.zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + inst * 1024), 16, 0, 0);
+      }
+    }
+  }
+}
+
+template <int EPI, int NT, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* __restrict__ Wt, bf16* __restrict__ Y,
                                                          int M, int N, int nk, size_t wrow_bytes, int ldo, int ntm,
                                                          int ntn, EpiArgs ea) {
@@ -66,18 +153,8 @@ __global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* 
   int lid = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (lid / ntn) * CV_BM, n0 = (lid % ntn) * (32 * NT);
 
-  // output-pixel coordinates of the 4 A-rows this lane gathers
-  int rt[4], rh[4], rw[4];
-  const int hw = g.Ho * g.Wo;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + (wave * 4 + i) * 8 + (lane >> 3);
-    m = m < M ? m : M - 1;
-    rt[i] = m / hw;
-    int rem = m - rt[i] * hw;
-    rh[i] = rem / g.Wo;
-    rw[i] = rem - rh[i] * g.Wo;
-  }
+  ConvRows<MODE> R;
+  conv_rows_init<MODE>(R, g, m0, M, wave, lane);
 
   f32x4 acc[NT][4];
 #pragma unroll
@@ -87,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* 
 
   auto stage = [&](int kt, int slot) {
     char* base = smem + slot * CV_STAGE;
-    stage_conv_rows(g, kt, base, wave, lane, rt, rh, rw);
+    stage_conv_rows<MODE>(R, g, kt, base, wave, lane);
     stage_rows(Wt, wrow_bytes, n0, N, kt * ROWB, base + CV_BM * ROWB, wave * 2, 2, lane);
   };
   stage(0, 0);
@@ -232,51 +309,58 @@ __global__ __launch_bounds__(256) void cl_to_tchw_clamp_kernel(const bf16* __res
 }
 
 // ===============================================================================================================
-extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* xcache, const ll_bf16* zero16, const ll_bf16* w,
-                          const ll_bf16* bias, const ll_bf16* res, ll_bf16* out, int T, int H, int W, int Cin, int Cout,
-                          int Kpad, int KT, int KH, int upsample, int ldo, ll_stream stream) {
+extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
+                          ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample,
+                          int ldo, ll_stream stream) {
   LL_REQUIRE(Cin > 0 && Cin % 8 == 0, "ll_conv_cl: Cin=%d must be a multiple of 8", Cin);
   LL_REQUIRE(Cout > 0 && Cout % 8 == 0, "ll_conv_cl: Cout=%d must be a multiple of 8 (pad the weights)", Cout);
   LL_REQUIRE((KT == 1 || KT == 3) && (KH == 1 || KH == 3), "ll_conv_cl: taps must be 1 or 3 (got %d x %d x %d)", KT, KH, KH);
-  LL_REQUIRE(upsample == 0 || upsample == 1, "ll_conv_cl: upsample must be 0 or 1");
-  LL_REQUIRE(KT == 1 || xcache != nullptr, "ll_conv_cl: a temporal convolution needs its 2-frame cache");
-  LL_REQUIRE(zero16 && bias, "ll_conv_cl: zero row and bias are required");
+  LL_REQUIRE(upsample == 0 || (upsample == 1 && KT == 1 && KH == 3), "ll_conv_cl: upsample is 0, or 1 with a 1x3x3 kernel");
+  LL_REQUIRE(x && zero16 && w && bias && out, "ll_conv_cl: null operand");
   const int taps = KT * KH * KH;
   const int nchunks = taps * (Cin / 8);
   LL_REQUIRE(Kpad % 64 == 0 && Kpad >= nchunks * 8 && Kpad < nchunks * 8 + 64, "ll_conv_cl: Kpad=%d does not match taps*Cin=%d", Kpad, nchunks * 8);
   LL_REQUIRE(nchunks < 4096, "ll_conv_cl: K too large for the chunk decoder");
   LL_REQUIRE(ldo >= Cout && ldo % 4 == 0, "ll_conv_cl: ldo=%d must be >= Cout and a multiple of 4", ldo);
+  const long long fb = (long long)H * W * Cin * 2;
+  LL_REQUIRE(3 * fb + 4ll * (W + 2) * Cin < (1ll << 31), "ll_conv_cl: frame of %lld bytes too large for 32-bit tap offsets", fb);
   const int Ho = upsample ? 2 * H : H, Wo = upsample ? 2 * W : W;
   const long long Mll = (long long)T * Ho * Wo;
   LL_REQUIRE(Mll > 0 && Mll < (1ll << 31), "ll_conv_cl: too many output pixels");
   const int M = (int)Mll;
   ConvGeo g;
-  g.x = (const char*)x; g.xc = (const char*)(xcache ? xcache : zero16); g.zero = (const char*)zero16;
+  g.x = (const char*)x; g.zero = (const char*)zero16;
   g.T = T; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.KT = KT; g.KH = KH; g.up = upsample;
-  g.cpt = Cin / 8; g.nchunks = nchunks; g.inv_cpt = (65536u + g.cpt - 1) / g.cpt;
+  g.cpt = Cin / 8; g.nchunks = nchunks; g.taps = taps; g.inv_cpt = (65536u + g.cpt - 1) / g.cpt;
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
   const int nk = Kpad / 64;
   const bool nt3 = (Cout % 96 == 0) && (Cout % 128 != 0), nt1 = Cout <= 32;
   const int bn = nt1 ? 32 : nt3 ? 96 : 128;
+  const int mode = Cin < 64 ? 0 : upsample ? 2 : 1;
   int ntm = (M + CV_BM - 1) / CV_BM, ntn = (Cout + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
   size_t lds = 3 * CV_STAGE;
   hipStream_t s = (hipStream_t)stream;
-#define CV_LAUNCH(E, NTV)                                                                                              \
+#define CV_LAUNCH(E, NTV, MD)                                                                                          \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)conv_cl_kernel<E, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)conv_cl_kernel<E, NTV, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((conv_cl_kernel<E, NTV>), grid, block, lds, s, g, (const char*)w, (bf16*)out, M, Cout, nk,       \
+    hipLaunchKernelGGL((conv_cl_kernel<E, NTV, MD>), grid, block, lds, s, g, (const char*)w, (bf16*)out, M, Cout, nk,   \
                        (size_t)Kpad * 2, ldo, ntm, ntn, ea);                                                           \
   } while (0)
+#define CV_MODES(E, NTV)                                                                                               \
+  do {                                                                                                                 \
+    if (mode == 0) CV_LAUNCH(E, NTV, 0); else if (mode == 1) CV_LAUNCH(E, NTV, 1); else CV_LAUNCH(E, NTV, 2);          \
+  } while (0)
   if (res) {
-    if (nt1) CV_LAUNCH(LL_EPI_BIAS_RES, 1); else if (nt3) CV_LAUNCH(LL_EPI_BIAS_RES, 3); else CV_LAUNCH(LL_EPI_BIAS_RES, 4);
+    if (nt1) CV_MODES(LL_EPI_BIAS_RES, 1); else if (nt3) CV_MODES(LL_EPI_BIAS_RES, 3); else CV_MODES(LL_EPI_BIAS_RES, 4);
   } else {
-    if (nt1) CV_LAUNCH(LL_EPI_BIAS, 1); else if (nt3) CV_LAUNCH(LL_EPI_BIAS, 3); else CV_LAUNCH(LL_EPI_BIAS, 4);
+    if (nt1) CV_MODES(LL_EPI_BIAS, 1); else if (nt3) CV_MODES(LL_EPI_BIAS, 3); else CV_MODES(LL_EPI_BIAS, 4);
   }
+#undef CV_MODES
 #undef CV_LAUNCH
   return ll_check_launch("ll_conv_cl");
 }

@@ -387,28 +387,31 @@ def pack_conv_weight(w: torch.Tensor, bias: torch.Tensor):
     return packed.contiguous(), b, (cin, cout8, kpad, kt, kh)
 
 
-def conv_cl(x, cache, packed, bias, geo, upsample: bool = False, res=None, out=None):
-    """x [T,H,W,Cin] channels-last; cache [2,H,W,Cin] or None (no temporal taps); packed/bias/geo from
+def conv_cl(x, packed, bias, geo, upsample: bool = False, res=None, out=None):
+    """Channels-last convolution.  Temporal kernels (kt == 3): x is [2 + T, H, W, Cin] -- the stream's previous two input
+    frames (zeros at its start) followed by the T new ones; otherwise x is [T, H, W, Cin].  packed/bias/geo from
     pack_conv_weight.  Returns [T, H<<up, W<<up, Cout8]."""
     cin, cout, kpad, kt, kh = geo
     _chk(x, "x"); _chk(packed, "w"); _chk(bias, "bias")
-    T, H, W, C = x.shape
+    hist = 2 if kt > 1 else 0
+    T, H, W, C = x.shape[0] - hist, x.shape[1], x.shape[2], x.shape[3]
+    assert T >= 1, "conv_cl: a temporal convolution takes [2 + T, H, W, Cin] (two history frames first)"
     assert C == cin, f"conv_cl: input has {C} channels, weights expect {cin}"
     assert packed.shape == (cout, kpad) and bias.numel() == cout
-    if kt > 1:
-        assert cache is not None and cache.shape == (2, H, W, cin), "conv_cl: temporal conv needs a [2,H,W,Cin] cache"
-        _chk(cache, "cache")
     Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
     if out is None:
         out = torch.empty(T, Ho, Wo, cout, dtype=bf16, device=x.device)
-    assert out.shape == (T, Ho, Wo, cout) and out.is_contiguous()
+    assert out.shape == (T, Ho, Wo, cout) and out.is_contiguous() and out.dtype == bf16
     if res is not None:
         _chk(res, "res")
         assert res.shape == out.shape
     lib = _lib.load()
-    _lib.check(lib.ll_conv_cl(x.data_ptr(), _ptr(cache if kt > 1 else None), zero_row(x.device).data_ptr(), packed.data_ptr(),
-                              bias.data_ptr(), _ptr(res), out.data_ptr(), T, H, W, cin, cout, kpad, kt, kh,
-                              1 if upsample else 0, cout, _stream()), "ll_conv_cl")
+    t0 = timer.begin("conv") if timer is not None else None
+    _lib.check(lib.ll_conv_cl(x[hist:].data_ptr(), zero_row(x.device).data_ptr(), packed.data_ptr(), bias.data_ptr(),
+                              _ptr(res), out.data_ptr(), T, H, W, cin, cout, kpad, kt, kh, 1 if upsample else 0, cout,
+                              _stream()), "ll_conv_cl")
+    if timer is not None:
+        timer.end("conv", t0, 2.0 * T * Ho * Wo * cout * (kt * kh * kh * cin))
     return out
 
 

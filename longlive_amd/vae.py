@@ -31,28 +31,41 @@ VAE_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.268
 
 
 class _Conv:
-    """One convolution: packed weights + (for temporal kernels) the 2-frame input cache (feat_cache, vae.py:29-34)."""
+    """One convolution: packed weights + (for temporal kernels) its input buffer [2 + T, H, W, Cin], whose first two frames
+    are the stream's previous two input frames -- the reference's feat_cache (vae.py:29-34, 207-216) -- kept in the layout
+    the kernel reads, so the history costs one 2-frame copy per call and no concatenation."""
 
     def __init__(self, w: torch.Tensor, b: torch.Tensor):
         self.w, self.b, self.geo = ops.pack_conv_weight(w, b)
         self.temporal = self.geo[3] > 1
-        self.cache: Optional[torch.Tensor] = None
+        self._hist: Optional[torch.Tensor] = None       # view of the last two input frames seen so far
+        self._buf: Optional[torch.Tensor] = None
 
     def reset(self):
-        self.cache = None
+        self._hist = None
+        self._buf = None
+
+    def input(self, T: int, H: int, W: int, device) -> torch.Tensor:
+        """Where the producer should write this convolution's T input frames."""
+        cin = self.geo[0]
+        if not self.temporal:
+            return torch.empty(T, H, W, cin, dtype=bf16, device=device)
+        buf = torch.empty(2 + T, H, W, cin, dtype=bf16, device=device)
+        if self._hist is None:
+            buf[:2].zero_()
+        else:
+            buf[:2].copy_(self._hist)
+        self._buf = buf
+        return buf[2:]
 
     def __call__(self, x: torch.Tensor, upsample: bool = False, res: Optional[torch.Tensor] = None) -> torch.Tensor:
         if not self.temporal:
-            return ops.conv_cl(x, None, self.w, self.b, self.geo, upsample=upsample, res=res)
-        if self.cache is None:
-            self.cache = torch.zeros(2, *x.shape[1:], dtype=bf16, device=x.device)
-        y = ops.conv_cl(x, self.cache, self.w, self.b, self.geo, upsample=upsample, res=res)
-        # cache <- the last two input frames of the stream so far (vae.py:207-216)
-        if x.shape[0] >= 2:
-            self.cache.copy_(x[-2:])
-        else:
-            self.cache[0].copy_(self.cache[1])
-            self.cache[1].copy_(x[0])
+            return ops.conv_cl(x, self.w, self.b, self.geo, upsample=upsample, res=res)
+        if self._buf is None or x.data_ptr() != self._buf[2:].data_ptr():
+            self.input(x.shape[0], x.shape[1], x.shape[2], x.device).copy_(x)     # producer did not write in place
+        buf, self._buf = self._buf, None
+        y = ops.conv_cl(buf, self.w, self.b, self.geo, upsample=upsample, res=res)
+        self._hist = buf[-2:]
         return y
 
 
@@ -130,11 +143,13 @@ class WanVAEDecoderHIP(nn.Module):
 
     # -- blocks ----------------------------------------------------------------------------------------------------
     def _res_block(self, x, name):                                       # ResidualBlock.forward (vae.py:202-220)
+        T, H, W, _ = x.shape
+        c1, c2 = self._convs[name + ".residual.2"], self._convs[name + ".residual.6"]
         h = self._convs[name + ".shortcut"](x) if (name + ".shortcut") in self._convs else x
-        y = ops.rms_silu_cl(x, self._gamma[name + ".residual.0.gamma"])
-        y = self._convs[name + ".residual.2"](y)
-        y = ops.rms_silu_cl(y, self._gamma[name + ".residual.3.gamma"])
-        return self._convs[name + ".residual.6"](y, res=h)
+        y = ops.rms_silu_cl(x, self._gamma[name + ".residual.0.gamma"], out=c1.input(T, H, W, x.device))
+        y = c1(y)
+        y = ops.rms_silu_cl(y, self._gamma[name + ".residual.3.gamma"], out=c2.input(T, H, W, x.device))
+        return c2(y, res=h)
 
     def _attn_block(self, x, name):                                      # AttentionBlock.forward (vae.py:240-262)
         a = self._attn[name]
@@ -175,8 +190,9 @@ class WanVAEDecoderHIP(nn.Module):
                 x = self._attn_block(x, L[1])
             else:
                 x = self._resample(x, L[1], L[0])
-        x = ops.rms_silu_cl(x, self._gamma["decoder.head.0.gamma"])
-        return self._convs["decoder.head.2"](x)                          # [T', H, W, 8] (3 channels + padding)
+        head = self._convs["decoder.head.2"]
+        x = ops.rms_silu_cl(x, self._gamma["decoder.head.0.gamma"], out=head.input(x.shape[0], x.shape[1], x.shape[2], x.device))
+        return head(x)                          # [T', H, W, 8] (3 channels + padding)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, keep_cache: bool = False) -> torch.Tensor:

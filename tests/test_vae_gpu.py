@@ -59,7 +59,7 @@ def test_conv_cl(ops, T, H, W, Cin, Cout, KT, KH, up, with_res):
     if with_res:
         res_cl = torch.zeros(T, want.shape[3], want.shape[4], geo[1], dtype=bf, device=DEV)
         res_cl[..., :Cout] = to_cl(res).to(DEV)
-    got = ops.conv_cl(to_cl(x).to(DEV), None if cache is None else to_cl(cache).to(DEV), pk, pb, geo, upsample=up, res=res_cl)
+    got = ops.conv_cl(to_cl(xin).to(DEV), pk, pb, geo, upsample=up, res=res_cl)      # history frames first when KT == 3
     torch.cuda.synchronize()
     assert got.shape[-1] == geo[1]
     # fp32 accumulation in a different order than the CPU conv: <= 1 ulp apart nearly everywhere
@@ -69,11 +69,10 @@ def test_conv_cl(ops, T, H, W, Cin, Cout, KT, KH, up, with_res):
 def test_conv_cl_rejects_bad_shapes(ops):
     w = hn("w", (96, 96, 3, 3, 3)).to(DEV)
     pk, pb, geo = ops.pack_conv_weight(w, torch.zeros(96, dtype=bf, device=DEV))
-    x = torch.zeros(1, 4, 4, 96, dtype=bf, device=DEV)
     with pytest.raises(AssertionError):
-        ops.conv_cl(x, None, pk, pb, geo)                                  # temporal conv without its cache
+        ops.conv_cl(torch.zeros(2, 4, 4, 96, dtype=bf, device=DEV), pk, pb, geo)   # temporal conv without room for its history
     with pytest.raises(AssertionError):
-        ops.conv_cl(torch.zeros(1, 4, 4, 64, dtype=bf, device=DEV), torch.zeros(2, 4, 4, 64, dtype=bf, device=DEV), pk, pb, geo)
+        ops.conv_cl(torch.zeros(3, 4, 4, 64, dtype=bf, device=DEV), pk, pb, geo)   # channel mismatch
 
 
 @pytest.mark.parametrize("C,pixels,silu", [(96, 1000, True), (192, 333, True), (384, 96, True), (384, 50, False)])
