@@ -118,6 +118,21 @@ class CausalInferencePipeline(nn.Module):
             yield start, denoised
 
     @torch.no_grad()
+    def stream_video(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None):
+        """Live form of `inference`: yields (start_frame, pixels[B, T', 3, H, W] in [0, 1]) after every block, decoding
+        each block with the VAE's streaming cache (WanVAE_.cached_decode, wan/modules/vae.py:571-593) -- the first block
+        gives 1 + 4 (F - 1) frames, later ones 4 F.  The concatenation equals `inference(...)`'s video bit for bit."""
+        if self.vae is None:
+            raise RuntimeError("stream_video needs a VAE (pass vae= to the pipeline)")
+        self.vae.model.clear_cache()
+        try:
+            for start, latents in self.stream(noise, text_prompts, output=output):
+                video = self.vae.decode_to_pixel(latents, use_cache=True)
+                yield start, (video * 0.5 + 0.5).clamp(0, 1)
+        finally:
+            self.vae.model.clear_cache()
+
+    @torch.no_grad()
     def inference(self, noise: torch.Tensor, text_prompts: List[str], return_latents: bool = False,
                   profile: bool = False, low_memory: bool = False):
         """noise [B, T, 16, H/8, W/8] -> video [B, T', 3, H, W] in [0,1] (None without a VAE) and, with

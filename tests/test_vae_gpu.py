@@ -164,3 +164,22 @@ def test_vae_decode_matches_oracle_on_other_geometry(vae):
     got = vae.decode_to_pixel(lat.to(DEV), use_cache=False).cpu()
     assert got.shape == want.shape
     assert rel_l2(got, want) < 3e-2
+
+
+def test_pipeline_streams_pixels_identical_to_one_shot_decode(vae):
+    """DiT (2 layers, 8x12 latents) + VAE through the pipeline: frames emitted live per block (streaming cache) are bit
+    identical to `inference()`'s decode of the finished latents, and the latents equal the VAE-less run."""
+    import test_model_gpu as TM
+    from longlive_amd.pipeline import CausalInferencePipeline
+    cfg, gen, enc = TM._pipe_generator()
+    noise = synth.synth_noise(cfg, 9, seed=41, device=DEV)
+    P = CausalInferencePipeline(TM._pipe_args(), DEV, generator=gen, text_encoder=enc, vae=vae)
+    P.randn_like = TM.TD.HashRandn(43)
+    video, lat = P.inference(noise, ["p0"], return_latents=True)
+    assert video.shape == (1, 33, 3, 64, 96) and float(video.min()) >= 0.0 and float(video.max()) <= 1.0
+    want = (vae.decode_to_pixel(lat, use_cache=False) * 0.5 + 0.5).clamp(0, 1)
+    assert torch.equal(video, want)
+    P.randn_like = TM.TD.HashRandn(43)
+    pieces = [px for _, px in P.stream_video(noise, ["p0"])]
+    assert [p.shape[1] for p in pieces] == [9, 12, 12]
+    assert torch.equal(torch.cat(pieces, 1), video)

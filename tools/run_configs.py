@@ -3,7 +3,9 @@
   config 3: 60-s single-prompt generation (T = 240 latent frames, sliding KV cache + frame sink)
   config 4: interactive multi-prompt stream (T = 240, 6 prompts, switches at 40,80,120,160,200, global_sink = false:
             configs/longlive_interactive_inference.yaml:21-27) exercising KV-recache on every switch.
-Random-init LongLive-1.3B weights, synthetic prompt embeddings / noise (longlive_amd.synth)."""
+  e2e     : with `--vae`, the same single-prompt stream with every block decoded live by the HIP VAE decoder
+            (pipeline.stream_video): generated pixel frames/s including the decode, and the latency of each block's frames.
+Random-init LongLive-1.3B / Wan-VAE weights, synthetic prompt embeddings / noise (longlive_amd.synth)."""
 import json
 import os
 import sys
@@ -27,7 +29,8 @@ def args(gs):
 
 
 def main():
-    T = int(sys.argv[1]) if len(sys.argv) > 1 else 240
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    T = int(argv[0]) if argv else 240
     dev = torch.device("cuda", 0)
     cfg = synth.longlive_1_3b(local_attn_size=12, sink_size=3)
     gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=dev,
@@ -61,6 +64,25 @@ def main():
         "switch_latency_ms": pr.get("switch_latency_ms"), "finite": bool(torch.isfinite(lat.float()).all()),
         "latent_std": float(lat.float().std()),
         "end_indices": [I.kv_cache1[0]["global_end_index"], I.kv_cache1[0]["local_end_index"]]}
+    if "--vae" in sys.argv:
+        from longlive_amd.vae import WanVAEWrapper
+        vcfg = synth.VaeConfig()
+        vae = WanVAEWrapper(vcfg, device=dev, chunk=3)
+        vae.load_state_dict(synth.synth_vae_state_dict(vcfg, seed=5, device=dev))
+        P = CausalInferencePipeline(args(True), dev, generator=gen, text_encoder=enc, vae=vae)
+        Te = min(T, 60)
+        times, frames = [], 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _, px in P.stream_video(noise[:, :Te], ["p0"]):
+            torch.cuda.synchronize()
+            times.append(time.perf_counter()); frames += px.shape[1]
+        dt = times[-1] - t0
+        steady = [(b - a) * 1e3 for a, b in zip(times[5:-1], times[6:])]       # full window from block 6 on
+        out["e2e_stream_video"] = {
+            "T_latent": Te, "pixel_frames": frames, "wall_s": dt, "fps_overall": frames / dt,
+            "steady_ms_per_block": sum(steady) / max(1, len(steady)),
+            "fps_steady_with_vae": 12e3 * len(steady) / sum(steady) if steady else None,
+            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
     print(json.dumps(out))
 
 
