@@ -282,3 +282,76 @@ def synth_vae_state_dict(cfg: VaeConfig, seed: int = 0, device="cpu", dtype=torc
             w = (hash_uniform(seed, name, shape, device) * 2.0 - 1.0) * math.sqrt(3.0 / fan_in)
         sd[name] = w.to(dtype)
     return sd
+
+
+# ---- umT5 text encoder ------------------------------------------------------------------
+@dataclass
+class T5Config:
+    """umt5_xxl encoder (wan/modules/t5.py:466-479): per-layer relative position embedding (shared_pos=False)."""
+    vocab_size: int = 256384
+    dim: int = 4096
+    dim_attn: int = 4096
+    dim_ffn: int = 10240
+    num_heads: int = 64
+    num_layers: int = 24
+    num_buckets: int = 32
+    text_len: int = 512
+    max_dist: int = 128
+
+
+def t5_param_shapes(cfg: T5Config) -> Dict[str, Tuple[int, ...]]:
+    """State-dict names of T5Encoder (wan/modules/t5.py:267-304)."""
+    sh: Dict[str, Tuple[int, ...]] = {"token_embedding.weight": (cfg.vocab_size, cfg.dim)}
+    for i in range(cfg.num_layers):
+        p = f"blocks.{i}."
+        sh[p + "norm1.weight"] = (cfg.dim,)
+        for n in "qkv":
+            sh[p + f"attn.{n}.weight"] = (cfg.dim_attn, cfg.dim)
+        sh[p + "attn.o.weight"] = (cfg.dim, cfg.dim_attn)
+        sh[p + "norm2.weight"] = (cfg.dim,)
+        sh[p + "ffn.gate.0.weight"] = (cfg.dim_ffn, cfg.dim)
+        sh[p + "ffn.fc1.weight"] = (cfg.dim_ffn, cfg.dim)
+        sh[p + "ffn.fc2.weight"] = (cfg.dim, cfg.dim_ffn)
+        sh[p + "pos_embedding.embedding.weight"] = (cfg.num_buckets, cfg.num_heads)
+    sh["norm.weight"] = (cfg.dim,)
+    return sh
+
+
+def synth_t5_state_dict(cfg: T5Config, seed: int = 0, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Random-init with the reference's init statistics (init_weights, t5.py:27-44); deviations so every term matters:
+    norm weights 1 + N(0,.1), q weights 8x larger (the reference's (dim*dim_attn)^-.5 makes all logits ~0), position
+    embeddings N(0, 1) (the reference's std .016 would make the relative bias invisible in bf16 parity)."""
+    head_dim = cfg.dim_attn // cfg.num_heads
+    sd = {}
+    for name, shape in t5_param_shapes(cfg).items():
+        z = hash_normal(seed, "t5." + name, shape, device)
+        if name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
+            w = 1.0 + 0.1 * z
+        elif name == "token_embedding.weight":
+            w = z
+        elif name.endswith("attn.q.weight"):
+            w = z * (cfg.dim ** -0.5) * (head_dim ** -0.25)
+        elif name.endswith(("attn.k.weight", "attn.v.weight", "gate.0.weight", "fc1.weight")):
+            w = z * cfg.dim ** -0.5
+        elif name.endswith("attn.o.weight"):
+            w = z * cfg.dim_attn ** -0.5
+        elif name.endswith("fc2.weight"):
+            w = z * cfg.dim_ffn ** -0.5
+        else:                                   # pos_embedding
+            w = z
+        sd[name] = w.to(dtype)
+    return sd
+
+
+def synth_token_ids(cfg: T5Config, n_tokens: int, seed: int = 0, batch: int = 1):
+    """(ids int64 [B, text_len] padded with 0, mask int64 [B, text_len]) as HuggingfaceTokenizer returns them
+    (wan/modules/tokenizers.py:52-73: padding='max_length')."""
+    u = hash_uniform(seed, "t5.ids", (batch, cfg.text_len))
+    ids = (u * (cfg.vocab_size - 2)).long() + 2
+    mask = torch.zeros(batch, cfg.text_len, dtype=torch.long)
+    for b in range(batch):
+        n = max(1, n_tokens - 3 * b)
+        mask[b, :n] = 1
+        ids[b, n - 1] = 1                      # </s>
+        ids[b, n:] = 0                         # <pad>
+    return ids, mask

@@ -452,6 +452,34 @@ def gen_vae(ns):
                                 stream_a=a.to(torch.bfloat16), stream_b=b.to(torch.bfloat16)))
 
 
+def gen_t5(ns):
+    """Reference T5Encoder (wan/modules/t5.py) built by the reference's own umt5_xxl(encoder_only=True, ...) factory, cast
+    to bf16 like inference.py:134, synthetic weights: (a) a tiny geometry, (b) the real widths (dim 4096, 64 heads,
+    ffn 10240, L = 512) with 2 layers and a 4096-entry vocabulary.  Output = WanTextEncoder.forward's post-processing
+    (padding rows zeroed, utils/wan_wrapper.py:52-53)."""
+    import importlib
+    t5 = importlib.import_module("wan.modules.t5")
+    rec = {}
+    for tag, cfg, ntok in (("tiny", synth.T5Config(vocab_size=512, dim=256, dim_attn=256, dim_ffn=512, num_heads=4, num_layers=3,
+                                                   text_len=64), 23),
+                           ("wide", synth.T5Config(vocab_size=4096, num_layers=2), 77)):
+        sd = synth.synth_t5_state_dict(cfg, seed=7)
+        model = t5.umt5_xxl(encoder_only=True, return_tokenizer=False, dtype=torch.float32, device=torch.device("cpu"),
+                            vocab_size=cfg.vocab_size, dim=cfg.dim, dim_attn=cfg.dim_attn, dim_ffn=cfg.dim_ffn,
+                            num_heads=cfg.num_heads, encoder_layers=cfg.num_layers).eval().requires_grad_(False)
+        model.load_state_dict({k: v.float() for k, v in sd.items()})
+        model = model.to(torch.bfloat16)
+        ids, mask = synth.synth_token_ids(cfg, ntok, seed=3, batch=2 if tag == "tiny" else 1)
+        t0 = time.time()
+        ctx = model(ids, mask)
+        seq_lens = mask.gt(0).sum(dim=1).long()
+        for u, v in zip(ctx, seq_lens):
+            u[v:] = 0.0
+        print(f"t5 {tag}: {time.time() - t0:.1f}s", tuple(ctx.shape), float(ctx.float().std()))
+        rec[tag] = dict(out=ctx.clone(), ntok=ntok)
+    _save("t5_enc.pt", rec)
+
+
 W_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,
           -0.1922, -0.9497, 0.2503, -0.2921]
 W_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382,
