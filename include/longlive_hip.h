@@ -178,6 +178,27 @@ int ll_vae_unscale_cl(const ll_bf16* z, const ll_bf16* mean, const ll_bf16* inv_
  * (wan/modules/vae.py decode's clamp_ + utils/wan_wrapper.py:112-116). */
 int ll_cl_to_tchw_clamp(const ll_bf16* x, float* out, int T, int H, int W, int ldc, ll_stream stream);
 
+/* ---- umT5 text encoder (wan/modules/t5.py, utils/wan_wrapper.py:16-57) ----------------- */
+
+/* T5LayerNorm.forward (wan/modules/t5.py:57-63): out = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))), fp32 statistics;
+ * x, out [rows, C] contiguous, any C % 8 == 0 (4096 for umT5-xxl). */
+int ll_t5_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, float eps, ll_stream stream);
+
+/* T5FeedForward's gated activation (t5.py:46-50,134-139): out[M,F] = bf16(h[:, F:2F] * GELU(h[:, 0:F])) with the
+ * reference's python tanh-GELU evaluated op by op in bf16; h [M, 2F] = x @ [gate.0.weight; fc1.weight]^T. */
+int ll_t5_gated_gelu(const ll_bf16* h, ll_bf16* out, long long M, int F, ll_stream stream);
+
+/* token_embedding(ids) (t5.py:297): out[i, :] = table[ids[i], :]; ids int64 on the device, validated by the caller. */
+int ll_gather_rows(const ll_bf16* table, const long long* ids, ll_bf16* out, int n, int C, long long vocab, ll_stream stream);
+
+/* T5Attention.forward (t5.py:85-117), self-attention of one sequence, head_dim 64, L in {64,128,256,512} keys = queries:
+ * out = bf16(softmax_fp32(bf16(bf16(q k^T) + bias), keys >= seq_len masked) v), no 1/sqrt(d) scaling.
+ * q,k [L, ...] with row stride ldqk (head h at columns h*64..); vt [H*64, L] = V transposed (x Wv^T computed as
+ * Wv x^T); bias_tab [H, 2L-1] with bias_tab[h, j - i + L - 1] = pos_embedding[bucket(j - i), h] (t5.py:219-263);
+ * out [L, ...] row stride ldo. */
+int ll_t5_attention(const ll_bf16* q, const ll_bf16* k, const ll_bf16* vt, const ll_bf16* bias_tab, ll_bf16* out, int L,
+                    int H, int ldqk, int ldo, int seq_len, ll_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,10 @@ SIGNATURES = {
     "ll_softmax_rows": [_p, _p, _i, _i, _i, _f, _p],
     "ll_vae_unscale_cl": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ll_cl_to_tchw_clamp": [_p, _p, _i, _i, _i, _i, _p],
+    "ll_t5_rmsnorm": [_p, _p, _p, _i, _i, _f, _p],
+    "ll_t5_gated_gelu": [_p, _p, _ll, _i, _p],
+    "ll_gather_rows": [_p, _p, _p, _i, _i, _ll, _p],
+    "ll_t5_attention": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 _RESTYPES = {"ll_last_error": C.c_char_p}
 

@@ -460,3 +460,51 @@ def cl_to_tchw_clamp(x):
     lib = _lib.load()
     _lib.check(lib.ll_cl_to_tchw_clamp(x.data_ptr(), out.data_ptr(), T, H, W, C, _stream()), "ll_cl_to_tchw_clamp")
     return out
+
+
+# ---- umT5 text encoder -----------------------------------------------------------------------------------------------
+def t5_rmsnorm(x, w, eps: float = 1e-6):
+    _chk(x, "x"); _chk(w, "w")
+    C = x.shape[-1]
+    assert w.numel() == C
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.ll_t5_rmsnorm(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.numel() // C, C, float(eps), _stream()),
+               "ll_t5_rmsnorm")
+    return out
+
+
+def t5_gated_gelu(h):
+    """h [M, 2F] = [gate | fc1] -> bf16(fc1 * GELU_py(gate)) [M, F]."""
+    _chk(h, "h")
+    M, F2 = h.numel() // h.shape[-1], h.shape[-1]
+    assert F2 % 16 == 0
+    out = torch.empty(*h.shape[:-1], F2 // 2, dtype=bf16, device=h.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_t5_gated_gelu(h.data_ptr(), out.data_ptr(), M, F2 // 2, _stream()), "ll_t5_gated_gelu")
+    return out
+
+
+def gather_rows(table, ids):
+    """table [V, C] bf16, ids int64 [n] on the device with 0 <= id < V (checked by the caller on the host copy)."""
+    _chk(table, "table"); _chk(ids, "ids", torch.int64)
+    V, C = table.shape
+    out = torch.empty(ids.numel(), C, dtype=bf16, device=table.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_gather_rows(table.data_ptr(), ids.data_ptr(), out.data_ptr(), ids.numel(), C, V, _stream()),
+               "ll_gather_rows")
+    return out
+
+
+def t5_attention(qk, vt, bias_tab, num_heads: int, seq_len: int):
+    """qk [L, 2*H*64] = [q | k] rows; vt [H*64, L]; bias_tab [H, 2L-1] -> [L, H*64]."""
+    _chk(qk, "qk"); _chk(vt, "vt"); _chk(bias_tab, "bias_tab")
+    L, two_c = qk.shape
+    C = num_heads * 64
+    assert two_c == 2 * C and vt.shape == (C, L) and bias_tab.shape == (num_heads, 2 * L - 1)
+    assert 1 <= seq_len <= L
+    out = torch.empty(L, C, dtype=bf16, device=qk.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_t5_attention(qk.data_ptr(), qk[:, C:].data_ptr(), vt.data_ptr(), bias_tab.data_ptr(), out.data_ptr(),
+                                   L, num_heads, two_c, C, int(seq_len), _stream()), "ll_t5_attention")
+    return out
