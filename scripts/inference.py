@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""`python scripts/inference.py --config_path configs/longlive_inference.yaml` -- the reference's inference.py on the MI355X path."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from longlive_amd.cli import main  # noqa: E402
+
+if __name__ == "__main__":
+    sys.exit(main(["inference"] + sys.argv[1:]))
