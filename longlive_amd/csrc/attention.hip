@@ -264,15 +264,25 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 #define PIPE_KSTAGES 2
 #define PIPE_VSTAGES 3
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
+// PP = 1: "ping-pong" schedule.  Waves w and w + 4 share a SIMD.  In the PP = 0 kernel every wave runs phase A (softmax of
+// tile t on the VALU with the S(t+1) MFMAs interleaved) and then phase B (P.V on the matrix pipe) in lock step between the
+// per-tile barriers, so the two waves of a SIMD contend for the VALU in A and for the matrix pipe in B: measured ~4150
+// cycles per tile against ~1050 VALU + ~1024 MFMA cycles of work per wave.  With PP the work of a tile is cut the other
+// way -- SM(t) = softmax(S(t)) (VALU only) and MM(t) = P(t).V(t) + S(t+1) = K(t+1).Q (32 MFMAs, no VALU) -- and waves 4..7
+// run half a tile behind: [SM(t), MM(t)] on waves 0..3 against [MM(t-1), SM(t)] on waves 4..7, so on every SIMD one wave
+// is on the VALU while the other is on the matrix pipe.  S(t+1) overwrites S(t) (no second score tile: 32 registers fewer).
+// Costs one more stage of K and of V (the late group still reads K(t), V(t-1) while tile t+2 is staged): 7 x 16 KiB of LDS,
+// one workgroup per CU (the grid has fewer workgroups than CUs anyway at Lq = 4680).
+template <int NW, int PP>
+__global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
                                                                      const bf16* __restrict__ Vc, bf16* __restrict__ O,
                                                                      int Lq, int ldq, int ldo, int ldk,
                                                                      long long k_batch_stride, int kstart, int nkeys,
                                                                      float c, int nqt, int xcd_placement) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K stage 0,1][V stage 0,1,2] x 16 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K stages][V stages] x 16 KiB
+  constexpr int KSTAGES = PIPE_KSTAGES + PP, VSTAGES = PIPE_VSTAGES + PP;
   char* const ksm = smem;
-  char* const vsm = smem + PIPE_KSTAGES * TILE_B;
+  char* const vsm = smem + KSTAGES * TILE_B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
@@ -280,6 +290,8 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
   // pairs, so one head's K/V stream is pulled into ~2 of the 8 L2s instead of all 8 (PMC: 8 x 57.5 MB per launch before).
   int nwg_ = gridDim.x, bid_ = blockIdx.x;
   int qq_ = nwg_ >> 3, rr_ = nwg_ & 7, xcd_ = bid_ & 7;
+  const int dbg_ = xcd_placement >> 8;   // experiments only: bit 0 skips SM, bit 1 skips MM (wrong results, timing)
+  xcd_placement &= 255;
   int lid_ = xcd_placement ? (xcd_ < rr_ ? xcd_ * (qq_ + 1) : rr_ * (qq_ + 1) + (xcd_ - rr_) * qq_) + (bid_ >> 3) : bid_;
   const int head = lid_ / nqt, qtile = lid_ % nqt;
   const int q0 = qtile * (NW * 32) + wave * 32;
@@ -298,34 +310,35 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
   }
 
-  constexpr int NCHUNK = 1024 / (NW * 64);
-  uint4 kr[NCHUNK], vr[NCHUNK];
-  // per-thread staging coordinates (loop invariant)
-  int st_goff[NCHUNK], st_koff[NCHUNK], st_voff[NCHUNK], st_key[NCHUNK];
+  // K/V staging by LDS-DMA (global_load_lds, 16 B per lane, no staging registers): instruction j of a tile fills LDS bytes
+  // [1024 j, 1024 (j+1)) linearly = keys 4j..4j+3; the lane at (key, pos) fetches the 16-byte chunk that the XOR swizzle
+  // puts there (K: pos ^ (key & 15); V: pos ^ ((key & 3) << 2)) -- the swizzle lives on the source side.  Each wave issues
+  // 16 / NW instructions for K and as many for V per tile.
+  constexpr int NDMA = 16 / NW;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int dma_key[NDMA], dma_kch[NDMA], dma_vch[NDMA];
 #pragma unroll
-  for (int i = 0; i < NCHUNK; ++i) {
-    int cid = tid + i * NW * 64;
-    int key = cid >> 4, ch = cid & 15;
-    st_key[i] = key;
-    st_goff[i] = ch * 8;
-    st_koff[i] = key * 256 + ((ch ^ (key & 15)) << 4);
-    st_voff[i] = key * 256 + ((ch ^ ((key & 3) << 2)) << 4);
+  for (int i = 0; i < NDMA; ++i) {
+    int key = 4 * (wave * NDMA + i) + (lane >> 4), pos = lane & 15;
+    dma_key[i] = key;
+    dma_kch[i] = (pos ^ (key & 15)) * 16;
+    dma_vch[i] = (pos ^ ((key & 3) << 2)) * 16;
   }
-#define PIPE_LOAD(T)                                                                             \
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define PIPE_DMA(T, KS, VS)                                                                      \
   {                                                                                              \
     int t_ = (T) < nt ? (T) : nt - 1;                                                            \
     int valid_ = (t_ == nt - 1) ? last_valid : KT;                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < NCHUNK; ++i_) {                                      \
-      int key_ = st_key[i_] < valid_ ? st_key[i_] : valid_ - 1;                                  \
-      size_t off_ = (size_t)(t_ * KT + key_) * ldk + st_goff[i_];                                \
-      kr[i_] = *reinterpret_cast<const uint4*>(kh + off_);                                       \
-      vr[i_] = *reinterpret_cast<const uint4*>(vh + off_);                                       \
+    const char* kt_ = reinterpret_cast<const char*>(kh) + (size_t)t_ * KT * ldk * 2;            \
+    const char* vt_ = reinterpret_cast<const char*>(vh) + (size_t)t_ * KT * ldk * 2;            \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDMA; ++i_) {                                        \
+      int key_ = dma_key[i_] < valid_ ? dma_key[i_] : valid_ - 1;                                \
+      unsigned row_ = (unsigned)key_ * (unsigned)ldk * 2u;                                       \
+      int j_ = wave_u * NDMA + i_;                                                               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kt_ + row_ + dma_kch[i_]), (lptr_t)(ksm + (KS) * TILE_B + j_ * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_ + row_ + dma_vch[i_]), (lptr_t)(vsm + (VS) * TILE_B + j_ * 1024), 16, 0, 0); \
     }                                                                                            \
-  }
-#define PIPE_STORE(KS, VS)                                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < NCHUNK; ++i_) {                                        \
-    *reinterpret_cast<uint4*>(ksm + (KS) * TILE_B + st_koff[i_]) = kr[i_];                       \
-    *reinterpret_cast<uint4*>(vsm + (VS) * TILE_B + st_voff[i_]) = vr[i_];                       \
   }
 
   // per-lane LDS read offsets (loop invariant; the stage base is added per iteration)
@@ -348,12 +361,11 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
   float m_run = -INFINITY, l_run = 0.f;
 
   // ---- prologue: tiles 0 and 1 into LDS, S(0) ------------------------------------------------------------------
-  PIPE_LOAD(0);
-  PIPE_STORE(0, 0);
-  PIPE_LOAD(1);
-  PIPE_STORE(1, 1);
+  PIPE_DMA(0, 0, 0);
+  PIPE_DMA(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  f32x16 s_cur[2], s_nxt[2];
+  f32x16 s_cur[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -367,115 +379,188 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
     }
   __syncthreads();   // K stage 0 is overwritten by iteration 0's staging: every wave must be done reading it
 
-  int vstage = 0;
-  for (int t = 0; t < nt; ++t) {
-    const char* kn = ksm + ((t + 1) & 1) * TILE_B;       // K(t+1)
-    const char* vc = vsm + vstage * TILE_B;              // V(t)
-    PIPE_LOAD(t + 2);                                    // global -> regs; written to LDS in phase B
-
-    if (t == nt - 1 && last_valid < KT) {                // ragged last tile: mask (uniform branch, own region)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-          if (key >= last_valid) s_cur[kb][i] = -INFINITY;
-        }
-    }
-
-    // ---- phase A: S(t+1) on the matrix pipe  ||  softmax(S(t)) on the VALU --------------------------------------
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s_nxt[kb][i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kn + k_off[ks] + kb * 8192);
-        s_nxt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_nxt[kb], 0, 0, 0);
-      }
-    float mx = s_cur[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_cur[kb][i]);
-    mx = xhalf_max(mx);
-    float m_new = fmaxf(m_run, mx);
-    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    float mc = m_new * c;
-    float rs = 0.f;
-    uint4 pw[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        float p[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));
-          rs += p[j];
-        }
-        pw[kb][s2] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]),
-                                pack_bf16x2(p[6], p[7]));
-      }
-    rs = xhalf_sum(rs);
-    l_run = l_run * alpha + rs;
+  // ---- phase A(t): S(t+1) on the matrix pipe  ||  softmax(S(t)) on the VALU; ends with s_cur = S(t+1) ------------------
 #ifdef LL_ATTN_SCHED
-    // pin the phase-A interleave: per MFMA one K-fragment read and a slice of the softmax VALU/transcendental work
-    // (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8, DS_READ 0x100, TRANS 0x400)
-#pragma unroll
-    for (int g_ = 0; g_ < 16; ++g_) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, LL_ATTN_SCHED, 0);
-      __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-    }
-#endif
-
-    if (__any(m_new != m_run)) {   // wave-uniform, exact: alpha == 1 in every lane otherwise
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-    }
-    m_run = m_new;
-
-    // ---- phase B: O^T += V(t)^T P(t)^T  ||  stage tile t+2 -------------------------------------------------------
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 pfrag = __builtin_bit_cast(bf16x8, pw[kb][s2]);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const char* a0 = vc + v_off[db] + (32 * kb + 16 * s2) * 256;
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 8 * 256));
-          typedef __attribute__((ext_vector_type(8))) short s16x8;
-          s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pfrag, o[db], 0, 0, 0);
-        }
-      }
-    {
-      int vs2 = vstage + 2;
-      vs2 = vs2 >= PIPE_VSTAGES ? vs2 - PIPE_VSTAGES : vs2;
-      PIPE_STORE(t & 1, vs2);      // K(t+2) over K(t) (read an iteration ago), V(t+2) over V(t-1)
-    }
-#ifdef LL_ATTN_SCHED_B
-    // phase-B interleave: per MFMA the two transposed V reads of the NEXT MFMA; staging writes spread behind them
-#pragma unroll
-    for (int g_ = 0; g_ < 16; ++g_) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-      __builtin_amdgcn_sched_group_barrier(0x002, LL_ATTN_SCHED_B, 1);
-    }
-#endif
-    __syncthreads();
-    s_cur[0] = s_nxt[0];
-    s_cur[1] = s_nxt[1];
-    vstage = vstage == PIPE_VSTAGES - 1 ? 0 : vstage + 1;
+  // pin the phase-A interleave: per MFMA one K-fragment read and a slice of the softmax VALU/transcendental work
+  // (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8, DS_READ 0x100, TRANS 0x400)
+#define PHASE_A_SCHED                                                                            \
+  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                           \
+    __builtin_amdgcn_sched_group_barrier(0x002, LL_ATTN_SCHED, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                                           \
   }
+#else
+#define PHASE_A_SCHED
+#endif
+#define PHASE_A(T)                                                                               \
+  {                                                                                              \
+    const char* kn = ksm + (((T) + 1) & 1) * TILE_B; /* K(t+1) */                                \
+    if ((T) == nt - 1 && last_valid < KT) { /* ragged last tile: mask (uniform branch) */        \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                           \
+        int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;                                      \
+        if (key >= last_valid) s_cur[kb][i] = -INFINITY;                                         \
+      }                                                                                          \
+    }                                                                                            \
+    f32x16 s_nxt[2];                                                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) s_nxt[kb][i] = 0.f;                           \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                           \
+      bf16x8 kf = *reinterpret_cast<const bf16x8*>(kn + k_off[ks] + kb * 8192);                  \
+      s_nxt[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_nxt[kb], 0, 0, 0);       \
+    }                                                                                            \
+    float mx = s_cur[0][0];                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_cur[kb][i]);                 \
+    mx = xhalf_max(mx);                                                                          \
+    float m_new = fmaxf(m_run, mx);                                                              \
+    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                   \
+    float mc = m_new * c;                                                                        \
+    float rs = 0.f;                                                                              \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                           \
+      float p[8];                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+        p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));            \
+        rs += p[j];                                                                              \
+      }                                                                                          \
+      pw[kb][s2] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), \
+                              pack_bf16x2(p[6], p[7]));                                          \
+    }                                                                                            \
+    rs = xhalf_sum(rs);                                                                          \
+    l_run = l_run * alpha + rs;                                                                  \
+    PHASE_A_SCHED                                                                                \
+    if (__any(m_new != m_run)) { /* wave-uniform, exact: alpha == 1 in every lane otherwise */   \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d)                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) o[d][i] *= alpha;                           \
+    }                                                                                            \
+    m_run = m_new;                                                                               \
+    s_cur[0] = s_nxt[0];                                                                         \
+    s_cur[1] = s_nxt[1];                                                                         \
+  }
+  // ---- phase B: O^T += V^T P^T with the P of the last phase A and the V stage VS ---------------------------------------
+#define PHASE_B(VS)                                                                              \
+  {                                                                                              \
+    const char* vc = vsm + (VS) * TILE_B;                                                        \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                           \
+      bf16x8 pfrag = __builtin_bit_cast(bf16x8, pw[kb][s2]);                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                         \
+        const char* a0 = vc + v_off[db] + (32 * kb + 16 * s2) * 256;                             \
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));                 \
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 8 * 256));       \
+        pp_s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                   \
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pfrag, o[db], 0, 0, 0); \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  typedef __attribute__((ext_vector_type(8))) short pp_s16x8;
+  uint4 pw[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) pw[kb][s2] = make_uint4(0, 0, 0, 0);
+  if constexpr (PP == 0) {
+    int vstage = 0;
+    for (int t = 0; t < nt; ++t) {
+      {                                                  // tile t+2: K over K(t) (read an interval ago), V over V(t-1)
+        int vs2 = vstage + 2;
+        vs2 = vs2 >= VSTAGES ? vs2 - VSTAGES : vs2;
+        PIPE_DMA(t + 2, t & 1, vs2);
+      }
+      PHASE_A(t);
+      PHASE_B(vstage);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile t+2 has landed in LDS
+      __syncthreads();
+      vstage = vstage == VSTAGES - 1 ? 0 : vstage + 1;
+    }
+  } else {
+    // SM(t): softmax of S(t) in s_cur -> P(t) in pw, running max / sum, O rescale.  VALU + transcendental only.
+#define PP_SM(T)                                                                                 \
+  {                                                                                              \
+    if ((T) == nt - 1 && last_valid < KT) {                                                      \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                           \
+        int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;                                      \
+        if (key >= last_valid) s_cur[kb][i] = -INFINITY;                                         \
+      }                                                                                          \
+    }                                                                                            \
+    float mx = s_cur[0][0];                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_cur[kb][i]);                 \
+    mx = xhalf_max(mx);                                                                          \
+    float m_new = fmaxf(m_run, mx);                                                              \
+    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                   \
+    float mc = m_new * c;                                                                        \
+    float rs = 0.f;                                                                              \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                           \
+      float p[8];                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+        p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));            \
+        rs += p[j];                                                                              \
+      }                                                                                          \
+      pw[kb][s2] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), \
+                              pack_bf16x2(p[6], p[7]));                                          \
+    }                                                                                            \
+    rs = xhalf_sum(rs);                                                                          \
+    l_run = l_run * alpha + rs;                                                                  \
+    if (__any(m_new != m_run)) {                                                                 \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d)                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) o[d][i] *= alpha;                           \
+    }                                                                                            \
+    m_run = m_new;                                                                               \
+  }
+    // MM: O^T += V(VS)^T P^T, then s_cur = K(KS) Q^T (the next score tile over the consumed one).  Matrix pipe + LDS reads.
+#define PP_MM(VS, KS)                                                                            \
+  {                                                                                              \
+    PHASE_B(VS);                                                                                 \
+    const char* kn = ksm + (KS) * TILE_B;                                                        \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) s_cur[kb][i] = 0.f;                           \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                           \
+      bf16x8 kf = *reinterpret_cast<const bf16x8*>(kn + k_off[ks] + kb * 8192);                  \
+      s_cur[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_cur[kb], 0, 0, 0);       \
+    }                                                                                            \
+    /* LDS reads eight MFMAs ahead (16 transposed V reads / 8 K reads in flight), not all up front (registers) */ \
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);                                          \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+  }
+    const int late = __builtin_amdgcn_readfirstlane(wave >= NW / 2);
+    if (late) __syncthreads();
+    int kq = 1, kd = 2, vq = 0, vd = 2;      // slots: K(t+1), K(t+2), V(t), V(t+2)
+    for (int t = 0; t < nt; ++t) {
+      PIPE_DMA(t + 2, kd, vd);
+      if (!(dbg_ & 1)) PP_SM(t);
+      __syncthreads();
+      __builtin_amdgcn_s_setprio(1);      // MM is the longer phase: its MFMA / LDS issue wins over the partner's softmax VALU
+      if (!(dbg_ & 2)) PP_MM(vq, kq);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      kq = kd;
+      kd = kd == KSTAGES - 1 ? 0 : kd + 1;
+      vq = vq == VSTAGES - 1 ? 0 : vq + 1;
+      vd = vd == VSTAGES - 1 ? 0 : vd + 1;
+    }
+    if (!late) __syncthreads();
+#undef PP_SM
+#undef PP_MM
+  }
+#undef PHASE_A
+#undef PHASE_B
+#undef PHASE_A_SCHED
 
   int qr = q0 + r;
   if (qr < Lq) {
@@ -493,7 +578,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_pipe_kernel(const bf16*
   }
 }
 
-static int g_attn_variant = 1;
+static int g_attn_variant = 2;   // 0: simple kernel, 1: software-pipelined, 2: + ping-pong wave groups for long key ranges
 static int g_attn_xcd = 1;
 void ll_set_attn_xcd_internal(int v) { g_attn_xcd = v; }   // 0: simple kernel, 1: software-pipelined kernel (single key range)
 void ll_set_attn_variant_internal(int v) { g_attn_variant = v; }
@@ -502,16 +587,24 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
                                          int Lq, int H, int ldq, int ldo, int ldk, long long k_batch_stride, int kstart,
                                          int nkeys, float c, ll_stream stream) {
   constexpr int NW = 8;
-  size_t lds = (PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B));
+    (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
     attr = true;
   }
   int nqt = (Lq + NW * 32 - 1) / (NW * 32);
   dim3 grid(nqt * H, 1, B), block(NW * 64);
-  hipLaunchKernelGGL(flash_attn_pipe_kernel<NW>, grid, block, lds, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
-                     (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
+  if (g_attn_variant >= 2 && nkeys >= 16 * KT)   // short ranges (cross-attention, 512 keys): the one-barrier loop is faster
+    hipLaunchKernelGGL((flash_attn_pipe_kernel<NW, 1>), grid, block, (PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B,
+                       (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
+                       k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
+  else
+    hipLaunchKernelGGL((flash_attn_pipe_kernel<NW, 0>), grid, block, (PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B,
+                       (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
+                       k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
   return ll_check_launch("ll_flash_attn(pipe)");
 }
 

@@ -210,8 +210,9 @@ int main(int argc, char** argv) {
    bench_gemm_i8("edge", 300, 136, 256, 2);
   }
   if (all || !strcmp(what, "attn")) {
-   for (int variant = 0; variant <= 1; ++variant) {
+   for (int variant = 0; variant <= 2; ++variant) {
     LL(ll_set_tuning("attn_variant", variant));
+    if (getenv("KB_ATTN_XCD")) LL(ll_set_tuning("attn_xcd", atoi(getenv("KB_ATTN_XCD"))));
     printf("-- attn_variant %d\n", variant);
     bench_attn("self", 4680, 12, 18720, 18720, iters);
     bench_attn("self-b1", 4680, 12, 18720, 9360, iters);
