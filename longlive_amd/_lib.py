@@ -56,11 +56,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("LONGLIVE_HIP_LIB", LIB_PATH)      # kernel A/B: another build of the same ABI
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is not built (make -C longlive_amd/csrc). "
+            f"{path} not found: the HIP extension is not built (make -C longlive_amd/csrc). "
             "longlive_amd has no CPU fallback by design.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
