@@ -538,7 +538,9 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
     const int late = __builtin_amdgcn_readfirstlane(wave >= NW / 2);
     // always true, but opaque to the compiler: each phase becomes its own basic block = its own scheduling region.  Without
     // it LLVM mixes the two phases' instructions across the barrier and the kernel is 15 % slower (594 vs 517 us in situ).
-    const bool own_block = xcd_placement >= 0;
+    const bool own_block = xcd_placement >= 0 && qtile * (NW * 32) + wave_u * 32 < Lq;   // ... and false for waves whose 32 query rows are all padding
+                                                            // (last q-tile): they only stage and sync -- the chip runs at
+                                                            // its power cap, an idle wave is clock for the others
     if (late) __syncthreads();
     int kq = 1, kd = 2, vq = 0, vd = 2;      // slots: K(t+1), K(t+2), V(t), V(t+2)
     for (int t = 0; t < nt; ++t) {

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
   if (nk > 1) stage(1, 1);
 
   const int fr = lane & 15, fg = lane >> 4;
+  const bool live = m0 + wm * 64 < M;       // wave-uniform
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed; tile kt+1 may be in flight
@@ -67,6 +68,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
     }
     const char* xs = smem + slot * V2_STAGE;
     const char* ws = xs + V2_BM * ROWB;
+    if (!live) { slot = slot == 2 ? 0 : slot + 1; continue; }   // rows past M (last m-tile): stage and sync only -- the chip
+                                                                // runs at its power cap, idle matrix pipes are speed elsewhere
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -123,12 +126,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict_
   stage(0, 0);
 
   const int fr = lane & 15, fg = lane >> 4;
+  const bool live = m0 + wm * 128 < M;      // wave-uniform
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // tile kt is in LDS for every wave; the other stage is no longer being read
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     const char* xs = smem + (kt & 1) * V3_STAGE;
     const char* ws = xs + V3_BM * ROWB;
+    if (!live) continue;               // rows past M: stage and sync only (see v2)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -153,6 +158,112 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict_
   }
   gemm_epilogue<EPI, I8, 4, 8>(acc, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, fr, fg, ea);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// v4: the 256 x 256 tile as a PING-PONG of the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w
+// and w + 4 share a SIMD).  A K-step is cut into four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each:
+//     [ds_read the quadrant's A (8 x b128) and/or B (4 x b128) fragments; 2 LDS-DMA pieces] s_barrier [16 MFMA] s_barrier
+// and the second group runs one barrier behind the first, so on every SIMD one wave is on the matrix pipe while its partner
+// fills registers from LDS (in v2/v3 both waves of a SIMD wait for LDS and then compete for the pipe at the same time).
+// Staging is spread evenly -- an LDS-DMA piece costs ~100 cycles of issue, 8 of them in one phase would starve the
+// partner's MFMA block -- by cutting a K-step's operands into four "half-tiles" along the quadrants:
+//     X0 / X1 = the A rows of every wave's first / second 64-row half,  Y0 / Y1 = the B rows of its first / second 32 columns
+// read in phases a | c (X0 | X1) and a,d | b (Y0 | Y1).  Each slot is restaged two phases after its last read and every
+// phase issues exactly one half-tile (2 pieces per wave):   a: X1(kt+1)   b: Y0(kt+1)   c: X0(kt+2)   d: Y1(kt+2)
+// so one counted wait per K-step -- vmcnt(4) in phase d, leaving only X0(kt+2), Y1(kt+2) in flight -- retires everything
+// K-step kt+1 reads, one barrier before its first read for either group.  Past the last K-step the source is clamped (the
+// piece count per phase must not change or the counted wait would retire the wrong loads); those pieces are never read.
+#define V4_LOAD_A(MH)                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+    int rx = wm * 128 + (MH) * 64 + t * 16 + fr;                                                 \
+    xf[t][ks] = *reinterpret_cast<const frag_t*>(xs + rx * ROWB + (((ks * 4 + fg) ^ (rx & 7)) << 4)); \
+  }
+#define V4_LOAD_B(NH)                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                \
+    int rw = wn * 64 + (NH) * 32 + t * 16 + fr;                                                  \
+    wf[t][ks] = *reinterpret_cast<const frag_t*>(ws + rw * ROWB + (((ks * 4 + fg) ^ (rw & 7)) << 4)); \
+  }
+#define V4_MMA(MH, NH)                                                                           \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                  \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                  \
+    acc[(NH) * 2 + a][(MH) * 4 + b] = Ty<I8>::mma(wf[a][ks], xf[b][ks], acc[(NH) * 2 + a][(MH) * 4 + b]); \
+  __builtin_amdgcn_s_setprio(0);                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_barrier();
+
+template <int EPI, bool I8>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict__ X, const char* __restrict__ Wt,
+                                                         bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, EpiArgs ea) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Ty<I8>::frag frag_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (lid / ntn) * V3_BM, n0 = (lid % ntn) * V3_BN;
+
+  typename Ty<I8>::acc acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = acc_zero<I8>();
+
+  // half-tile staging: which 2 of the operand's 32 eight-row pieces this wave copies
+  const int xi = (wave < 4 ? 2 * wave : 16 + 2 * (wave - 4));        // X0: rows 0-63 | 128-191 (X1: + 8 pieces)
+  const int yi = (wave >> 1) * 8 + (wave & 1) * 2;                   // Y0: rows 0-31 | 64-95 | 128-159 | 192-223 (Y1: + 4)
+  auto stage_x = [&](int kt, int half) {
+    int kc = kt < nk ? kt : nk - 1;
+    stage_rows(X, xrow_bytes, m0, M, kc * ROWB, smem + (kt & 1) * V3_STAGE, xi + half * 8, 2, lane);
+  };
+  auto stage_y = [&](int kt, int half) {
+    int kc = kt < nk ? kt : nk - 1;
+    stage_rows(Wt, wrow_bytes, n0, N, kc * ROWB, smem + (kt & 1) * V3_STAGE + V3_BM * ROWB, yi + half * 4, 2, lane);
+  };
+  stage_x(0, 0); stage_y(0, 1); stage_x(0, 1); stage_y(0, 0);       // K-step 0
+  stage_x(1, 0); stage_y(1, 1);                                     // what phases c, d of K-step -1 would have issued
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();      // the second group runs one barrier behind
+
+  const int fr = lane & 15, fg = lane >> 4;
+  frag_t xf[4][2], wf[2][2];
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* xs = smem + (kt & 1) * V3_STAGE;
+    const char* ws = xs + V3_BM * ROWB;
+    // phase a: rows 0-63 x cols 0-31 of the wave tile
+    V4_LOAD_B(0);
+    V4_LOAD_A(0);
+    stage_x(kt + 1, 1);
+    V4_MMA(0, 0);
+    // phase b: rows 0-63 x cols 32-63
+    V4_LOAD_B(1);
+    stage_y(kt + 1, 0);
+    V4_MMA(0, 1);
+    // phase c: rows 64-127 x cols 32-63
+    V4_LOAD_A(1);
+    stage_x(kt + 2, 0);
+    V4_MMA(1, 1);
+    // phase d: rows 64-127 x cols 0-31
+    V4_LOAD_B(0);
+    stage_y(kt + 2, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    V4_MMA(1, 0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  gemm_epilogue<EPI, I8, 4, 8>(acc, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, fr, fg, ea);
+}
+#undef V4_LOAD_A
+#undef V4_LOAD_B
+#undef V4_MMA
 
 // runtime tuning switches (A/B experiments from tools/kbench; defaults are the shipped configuration)
 static int g_gemm_variant = 0;
@@ -248,18 +359,27 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
                        int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
   const int kbytes = I8 ? K : 2 * K;
   const int nk = kbytes / ROWB;
-  // variant 2 = 256x128 / 3-stage ring, 3 = 256x256 / 128x64 per wave; 0 = auto: the 256x256 tile only where it still
-  // fills the chip (N >= 4096), else variant 2.
+  // variant 2 = 256x128 / 3-stage ring, 3 = 256x256 / 128x64 per wave, 4 = 256x256 ping-pong; 0 = auto: the 256x256 tile
+  // (ping-pong) only where it still fills the chip (N >= 4096), else variant 2.
   int variant = g_gemm_variant;
-  if (variant != 2 && variant != 3) variant = (N >= 4096 && M >= 2048) ? 3 : 2;
-  const bool v3 = (variant == 3);
+  if (variant != 2 && variant != 3 && variant != 4) variant = (N >= 4096 && M >= 2048) ? 3 : 2;
+  const bool v4 = (variant == 4);
+  const bool v3 = (variant == 3) || v4;      // same tile and LDS footprint
   int bm = v3 ? V3_BM : V2_BM, bn = v3 ? V3_BN : BN;
   int ntm = (M + bm - 1) / bm, ntn = (N + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
   size_t lds = v3 ? 2 * V3_STAGE : 3 * V2_STAGE;
 #define LAUNCH(E)                                                                                                      \
   do {                                                                                                                 \
-    if (v3) {                                                                                                          \
+    if (v4) {                                                                                                          \
+      static bool a4 = false;                                                                                          \
+      if (!a4) {                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        a4 = true;                                                                                                     \
+      }                                                                                                                \
+      hipLaunchKernelGGL((gemm_kernel_v4<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                   \
+    } else if (v3) {                                                                                                   \
       static bool a3 = false;                                                                                          \
       if (!a3) {                                                                                                       \
         (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
