@@ -242,10 +242,14 @@ class CausalWanModelHIP(nn.Module):
     @torch.no_grad()
     def forward_frames(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, kv_cache: List[dict],
                        crossattn_cache: List[dict], current_start: int = 0,
-                       sink_recache_after_switch: bool = False, sigma: Optional[torch.Tensor] = None):
+                       sink_recache_after_switch: bool = False, sigma: Optional[torch.Tensor] = None,
+                       kv_only: bool = False):
         """x [B,F,Cin,H,W] (the wrapper's layout); t [B,F]; context [B,text_len,text_dim].
         Returns the head output [B, L, 4*Cout] (pre-unpatchify), or (flow, x0) in [B,F,C,H,W] when `sigma`
-        (float32 [B*F]) is given."""
+        (float32 [B*F]) is given.  kv_only: the caller discards the output and only wants the KV caches updated (the
+        clean-context pass and the recache pass, causal_inference.py:192-200, interactive_causal_inference.py:34-106):
+        everything after the last layer's K/V insert -- its attention, cross-attention, FFN and the head -- is skipped and
+        None is returned; the caches end up bit-identical."""
         c = self.cfg
         B, F, Cin, H, W = x.shape
         hp, wp = H // 2, W // 2
@@ -282,6 +286,8 @@ class CausalWanModelHIP(nn.Module):
             ops.qk_norm_rope_kv_store(qkv, sa.norm_q.weight, sa.norm_k.weight, rope_f, rope_hw, q_buf.view(B, L, C),
                                       kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
                                       plan.roped_offset, plan.write_len, c.eps)
+            if kv_only and i == len(self.blocks) - 1:
+                break
             att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
             self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
                      mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
@@ -306,6 +312,8 @@ class CausalWanModelHIP(nn.Module):
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)
+        if kv_only:
+            return (None, None) if sigma is not None else None
         # --- head (causal_model.py:497-508,1065) ---
         eh = e.view(B, F, 1, C).expand(B, F, 2, C).contiguous()
         hd = ops.ln_modulate(xs, eh, self.head.modulation.view(2, C), 0, 1, F, c.eps)

@@ -82,12 +82,18 @@ class CausalInferencePipeline(nn.Module):
                 noisy_input = self.scheduler.add_noise(flat, self.randn_like(flat), nxt).unflatten(0, denoised.shape[:2])
         return denoised
 
+    def _kv_only_kw(self) -> dict:
+        """The output of the clean-context / recache pass is discarded (causal_inference.py:192-200): a generator that can
+        stop after the last layer's K/V insert is told so.  Any other generator gets the reference's exact call."""
+        return {"kv_only": True} if getattr(self.generator, "supports_kv_only", False) else {}
+
     def _clean_context_pass(self, denoised, cond, start_frame: int):
         """Re-run at t = context_noise so the cache holds clean-frame K/V (causal_inference.py:192-200)."""
         B, nf = denoised.shape[:2]
         ctx_t = self._timestep(float(getattr(self.args, "context_noise", 0)), B, nf, denoised.device)
         self.generator(noisy_image_or_video=denoised, conditional_dict=cond, timestep=ctx_t, kv_cache=self.kv_cache1,
-                       crossattn_cache=self.crossattn_cache, current_start=start_frame * self.frame_seq_length)
+                       crossattn_cache=self.crossattn_cache, current_start=start_frame * self.frame_seq_length,
+                       **self._kv_only_kw())
 
     def _setup(self, noise, num_output_frames):
         local_attn_cfg = _mk(self.args, "local_attn_size", -1)

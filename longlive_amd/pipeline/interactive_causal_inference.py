@@ -42,7 +42,7 @@ class InteractiveCausalInferencePipeline(CausalInferencePipeline):
             num_frame_per_block=self.num_frame_per_block, local_attn_size=self.local_attn_size)
         self.generator(noisy_image_or_video=frames, conditional_dict=new_conditional_dict, timestep=ctx_t,
                        kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
-                       current_start=start * self.frame_seq_length, sink_recache_after_switch=not self.global_sink)
+                       current_start=start * self.frame_seq_length, sink_recache_after_switch=not self.global_sink, **self._kv_only_kw())
         self._reset_crossattn()
 
     @torch.no_grad()

@@ -42,14 +42,17 @@ class WanDiffusionWrapper(nn.Module):
     def get_scheduler(self) -> FlowMatchScheduler:
         return self.scheduler
 
+    supports_kv_only = True      # the pipelines pass kv_only=True for passes whose output they discard
+
     @torch.no_grad()
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
                 kv_cache: Optional[List[dict]] = None, crossattn_cache: Optional[List[dict]] = None,
                 current_start: Optional[int] = None, classify_mode: Optional[bool] = False,
                 concat_time_embeddings: Optional[bool] = False, clean_x: Optional[torch.Tensor] = None,
                 aug_t: Optional[torch.Tensor] = None, cache_start: Optional[int] = None,
-                sink_recache_after_switch: bool = False):
-        """noisy [B,F,16,H,W], timestep [B,F] -> (flow_pred, pred_x0), both [B,F,16,H,W]."""
+                sink_recache_after_switch: bool = False, kv_only: bool = False):
+        """noisy [B,F,16,H,W], timestep [B,F] -> (flow_pred, pred_x0), both [B,F,16,H,W].  kv_only (not in the reference's
+        signature; default off): only update the KV caches, return (None, None) -- see CausalWanModelHIP.forward_frames."""
         if kv_cache is None or classify_mode or clean_x is not None:
             raise NotImplementedError("only the KV-cache inference call is implemented (SURVEY.md section 8a)")
         prompt_embeds = conditional_dict["prompt_embeds"]
@@ -58,6 +61,9 @@ class WanDiffusionWrapper(nn.Module):
         t = timestep.to(dev)
         sigma = self.scheduler.sigma_of(t)                                              # wan_wrapper.py:195-197
         flow, x0 = self.model.forward_frames(x, t, prompt_embeds.to(dev), kv_cache, crossattn_cache,
-                                             int(current_start or 0), sink_recache_after_switch, sigma=sigma)
+                                             int(current_start or 0), sink_recache_after_switch, sigma=sigma,
+                                             kv_only=kv_only)
+        if kv_only:
+            return None, None
         dt = noisy_image_or_video.dtype
         return flow.to(dt), x0.to(dt)

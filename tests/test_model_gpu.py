@@ -238,3 +238,23 @@ def test_int8_linears_vs_bf16_path():
           f"int8 vs reference bf16: {rel_l2(outs['int8'], rec['flow_block0']):.2e}")
     assert r < 6e-2 and cosine(outs["int8"], outs[None]) > 0.998
     assert rel_l2(outs["int8"], rec["flow_block0"]) < 7e-2
+
+
+def test_kv_only_context_pass_is_bit_identical():
+    """The clean-context / recache passes stop after the last layer's K/V insert (kv_only): same latents, same caches, same
+    end indices as running those passes in full (what the reference does and then discards)."""
+    from longlive_amd.pipeline import InteractiveCausalInferencePipeline
+    cfg, gen, enc = _pipe_generator()
+    noise = synth.synth_noise(cfg, 12, seed=45, device=DEV)
+    outs = []
+    for flag in (True, False):
+        gen.supports_kv_only = flag
+        I = InteractiveCausalInferencePipeline(_pipe_args(False), DEV, generator=gen, text_encoder=enc)
+        I.randn_like = TD.HashRandn(47)
+        _, lat = I.inference(noise, text_prompts_list=[["p0"], ["p1"]], switch_frame_indices=[6], return_latents=True)
+        outs.append((lat.clone(), [kv["k"].clone() for kv in I.kv_cache1], [kv["v"].clone() for kv in I.kv_cache1],
+                     (I.kv_cache1[0]["global_end_index"], I.kv_cache1[0]["local_end_index"])))
+    gen.supports_kv_only = True
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][3] == outs[1][3]
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert torch.equal(a, b)
