@@ -175,7 +175,7 @@ def main():
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "flash_attn_pipe_kernel<8> (self-attention, Lq=4680, Lk=18720, 12 heads)", "achieved": achieved,
+            roof = {"bound": "mfma", "kernel": "flash_attn_pipe_kernel<8, 1> (self-attention, ping-pong wave groups, Lq=4680, Lk=18720, 12 heads)", "achieved": achieved,
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
                     "traffic": traffic, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
                     "flop_per_launch": s["work_per_launch"],
