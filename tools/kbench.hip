@@ -215,6 +215,7 @@ int main(int argc, char** argv) {
     if (getenv("KB_ATTN_XCD")) LL(ll_set_tuning("attn_xcd", atoi(getenv("KB_ATTN_XCD"))));
     printf("-- attn_variant %d\n", variant);
     bench_attn("self", 4680, 12, 18720, 18720, iters);
+    if (getenv("KBENCH_SELF_ONLY")) continue;          // PMC passes: only the steady-state self-attention launch
     bench_attn("self-b1", 4680, 12, 18720, 9360, iters);
     bench_attn("cross", 4680, 12, 512, 512, iters);
     bench_attn("ragged", 200, 2, 300, 157, 3);
