@@ -290,7 +290,21 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
   // pairs, so one head's K/V stream is pulled into ~2 of the 8 L2s instead of all 8 (PMC: 8 x 57.5 MB per launch before).
   int nwg_ = gridDim.x, bid_ = blockIdx.x;
   int qq_ = nwg_ >> 3, rr_ = nwg_ & 7, xcd_ = bid_ & 7;
-  int lid_ = xcd_placement ? (xcd_ < rr_ ? xcd_ * (qq_ + 1) : rr_ * (qq_ + 1) + (xcd_ - rr_) * qq_) + (bid_ >> 3) : bid_;
+  // The rr_ XCDs that hold one workgroup more than the others are spread evenly over the id range (ranges of 29, 28, 29, 28 ...
+  // rather than 29 x 4, 28 x 4): with 12 heads x 19 q-tiles the range boundaries then fall on multiples of 9.5 q-tiles, every
+  // head meets at most two XCDs without one-tile slivers, 16 (head, XCD) pairs instead of 19.  Still a bijection.
+  int lid_ = bid_;
+  if (xcd_placement) {
+    int start_ = 0, nbig_ = 0, nsmall_ = 0, mine_ = 0;
+#pragma unroll
+    for (int k_ = 0; k_ < 8; ++k_) {
+      bool big_ = ((k_ + 1) * rr_) / 8 > (k_ * rr_) / 8;
+      int id_ = big_ ? nbig_++ : rr_ + nsmall_++;
+      mine_ = id_ == xcd_ ? start_ : mine_;
+      start_ += big_ ? qq_ + 1 : qq_;
+    }
+    lid_ = mine_ + (bid_ >> 3);
+  }
   const int head = lid_ / nqt, qtile = lid_ % nqt;
   const int q0 = qtile * (NW * 32) + wave * 32;
   const int nt = (nkeys + KT - 1) / KT;
