@@ -172,6 +172,9 @@ def test_linear_small_time_embedding(ops):
     (1, 130, 12, 512, [(0, 512)]),                      # cross-attention shape
     (1, 1560, 12, 4680, [(0, 1560), (1560, 4680)]),     # adjacent ranges merge; real head count
     (1, 33, 1, 7, [(0, 7)]),                            # fewer keys than one tile
+    (2, 300, 3, 1500, [(0, 1437)]),                     # >= 1024 keys: ping-pong kernel; batch 2, ragged keys, padded waves
+    (1, 64, 1, 1024, [(0, 1024)]),                      # exactly at the ping-pong threshold, all but two waves padding
+    (1, 257, 2, 2000, [(37, 1100)]),                    # ping-pong with a key range that does not start at slot 0
 ])
 def test_flash_attn(ops, B, Lq, H, Sk, segs):
     q = hn("aq", (B, Lq, H, 128))
