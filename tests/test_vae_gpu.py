@@ -183,3 +183,19 @@ def test_pipeline_streams_pixels_identical_to_one_shot_decode(vae):
     pieces = [px for _, px in P.stream_video(noise, ["p0"])]
     assert [p.shape[1] for p in pieces] == [9, 12, 12]
     assert torch.equal(torch.cat(pieces, 1), video)
+
+
+def test_vae_first_frame_at_real_resolution_matches_oracle(vae):
+    """One latent frame at 60x104 -> 480x832 against the CPU oracle (a few seconds on the host): exercises the real tile
+    counts (399360-pixel convolutions, 6240-token attention, every upsample) that the small goldens do not."""
+    from oracle import ref_vae as RV
+    vcfg = synth.VaeConfig()
+    _, layers = synth.vae_decoder_layout(vcfg)
+    dec = RV.RefVaeDecoder(synth.synth_vae_state_dict(vcfg, seed=5), layers)
+    lat = synth.hash_normal(57, "vae.latent3", (1, 1, 16, 60, 104)).to(bf)
+    want = RV.decode_to_pixel(dec, lat, use_cache=False)
+    got = vae.decode_to_pixel(lat.to(DEV), use_cache=False).cpu()
+    assert got.shape == want.shape == (1, 1, 3, 480, 832)
+    r = rel_l2(got, want)
+    print(f"vae 480x832 first frame rel-L2 {r:.2e}")
+    assert r < 3e-2
