@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2, help="layers of one steady-state forward timed on the CPU")
+    ap.add_argument("--workload", choices=["dit", "vae", "t5"], default="dit",
+                    help="dit (default): the headline metric.  vae / t5: the section-8f rows (VAE decoder, umT5 encoder) with "
+                         "their own roofline and cpu_baseline objects; single GPU, not the driver's metric")
     ap.add_argument("--quant", choices=["none", "int8"], default="none",
                     help="int8: W8A8 block linears (BASELINE config 5); the headline metric is the default bf16 path")
     return ap.parse_args()
@@ -88,8 +91,56 @@ def cpu_baseline(num_layers_sample: int):
                        f"layers x5 forwards per 12-frame block")
 
 
+def cpu_baseline_vae(vae, lat):
+    """The oracle (oracle/ref_vae.py) decoding the FIRST latent frame (one 480x832 pixel frame, 3.4 TFLOP) on the host."""
+    from longlive_amd import synth
+    from oracle import ref_vae as RV
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    _, layers = synth.vae_decoder_layout(vae.model.cfg)
+    dec = RV.RefVaeDecoder({k: v.cpu() for k, v in vae.model.state_dict().items()}, layers)
+    t0 = time.perf_counter()
+    ref = RV.decode_to_pixel(dec, lat[:, :1].cpu(), use_cache=False)
+    dt = time.perf_counter() - t0
+    return {"value": ref.shape[1] / dt, "unit": "pixel frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle decode of the first latent frame (1 pixel frame at 480x832), %.1f s" % dt}
+
+
+def cpu_baseline_t5(enc, cfg, ids, mask):
+    """The oracle (oracle/ref_t5.py) on 2 of the 24 layers at the real widths, extrapolated x12."""
+    from oracle import ref_t5 as RT
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    sd = {k: v.cpu() for k, v in enc.text_encoder.state_dict().items()
+          if not k.startswith("blocks.") or int(k.split(".")[1]) < 2}
+    t0 = time.perf_counter()
+    RT.text_encoder_forward(ids, mask, sd, 2, cfg.num_heads)
+    dt = (time.perf_counter() - t0) * cfg.num_layers / 2
+    return {"value": 1e3 * dt, "unit": "ms per prompt", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle on 2 of 24 layers, extrapolated x12"}
+
+
+def side_workload(args):
+    """`--workload vae|t5`: tools/vae_bench.py / tools/t5_bench.py (HIP path, roofline) + the CPU baseline leg, which
+    lives here because only bench.py may run the oracle outside tests."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if args.workload == "vae":
+        import vae_bench
+        rec, vae, lat = vae_bench.run(9, 2)
+        if not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline_vae(vae, lat)
+    else:
+        import t5_bench
+        rec, enc, cfg, ids, mask = t5_bench.run(5)
+        if not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline_t5(enc, cfg, ids, mask)
+    print(json.dumps(rec), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload != "dit":
+        return side_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

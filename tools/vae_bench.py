@@ -1,8 +1,7 @@
 """Times the HIP VAE decoder at the real geometry (60x104 latents -> 480x832 pixels), synthetic weights.
-usage: python tools/vae_bench.py [latent_frames=9] [chunk=2] [--cpu]   (prints one JSON line)
+usage: python tools/vae_bench.py [latent_frames=9] [chunk=2]   (prints one JSON line)
 roofline: all ll_conv_cl launches of the timed region (HIP events on the launch stream), algorithmic FLOPs / time against
-the 2.5 PFLOP/s bf16 MFMA peak.  --cpu adds the CPU baseline: the oracle (oracle/ref_vae.py) decoding the FIRST latent
-frame (one 480x832 pixel frame, 3.2 TFLOP) on the host's cores."""
+the 2.5 PFLOP/s bf16 MFMA peak.  `python bench.py --workload vae` prints the same record plus the CPU baseline."""
 import json
 import os
 import sys
@@ -40,10 +39,7 @@ def conv_flops(cfg, h, w):
     return fl
 
 
-def main():
-    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
-    n = int(argv[0]) if argv else 9
-    chunk = int(argv[1]) if len(argv) > 1 else 2
+def run(n: int = 9, chunk: int = 2):
     cfg = synth.VaeConfig()
     vae = WanVAEWrapper(cfg, device="cuda", chunk=chunk)
     vae.load_state_dict(synth.synth_vae_state_dict(cfg, seed=5, device="cuda"))
@@ -70,16 +66,12 @@ def main():
            "roofline": {"bound": "mfma", "kernel": "conv_cl_kernel (all implicit-GEMM convolutions of the timed region)",
                         "achieved": conv_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": conv_tf / 2500.0,
                         "launches": ksum["launches"], "share_of_time": ksum["total_ms"] * 1e-3 / dt}}
-    if "--cpu" in sys.argv:
-        from oracle import ref_vae as RV
-        torch.set_num_threads(min(os.cpu_count() or 1, 16))
-        _, layers = synth.vae_decoder_layout(cfg)
-        dec = RV.RefVaeDecoder({k: v.cpu() for k, v in vae.model.state_dict().items()}, layers)
-        t0 = time.perf_counter()
-        ref = RV.decode_to_pixel(dec, lat[:, :1].cpu(), use_cache=False)
-        cdt = time.perf_counter() - t0
-        rec["cpu_baseline"] = {"value": ref.shape[1] / cdt, "unit": "pixel frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": "oracle decode of the first latent frame (1 pixel frame at 480x832), %.1f s" % cdt}
+    return rec, vae, lat
+
+
+def main():
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rec, _, _ = run(int(argv[0]) if argv else 9, int(argv[1]) if len(argv) > 1 else 2)
     print(json.dumps(rec))
 
 
