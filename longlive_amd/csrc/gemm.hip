@@ -160,6 +160,73 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// v5: v3's structure (256 rows, 2-stage ring, one barrier per K-step) with the column width as a parameter, for shapes where
+// 256-column tiles quantise badly on 256 CUs: WM x WN waves of (MT x NT) 16 x 16 tiles, BN = WN * NT * 16.
+//   <2, 4, 8, 3>: 256 x 192 (QKV, N = 4608: 456 tiles = 2 rounds of 0.75 instead of 342 = 2 rounds of 1.0)
+//   <4, 2, 4, 7>: 256 x 224 (FFN1, N = 8960: 760 tiles = 2.97 rounds of 0.875 instead of 665 = 3 rounds of 1.0)
+template <int EPI, bool I8, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict__ X, const char* __restrict__ Wt,
+                                                         bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, EpiArgs ea) {
+  static_assert(WM * WN == 8 && WM * MT * 16 == 256, "8 waves, 256 rows");
+  constexpr int BNv = WN * NT * 16, STAGE = (256 + BNv) * ROWB, NB = BNv / 8;   // NB = B pieces of 8 rows per K-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Ty<I8>::frag frag_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (lid / ntn) * 256, n0 = (lid % ntn) * BNv;
+
+  typename Ty<I8>::acc acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = acc_zero<I8>();
+
+  auto stage = [&](int kt, int slot) {
+    char* base = smem + slot * STAGE;
+    stage_rows(X, xrow_bytes, m0, M, kt * ROWB, base, wave * 4, 4, lane);
+    stage_rows(Wt, wrow_bytes, n0, N, kt * ROWB, base + 256 * ROWB, wave * (NB / 8), NB / 8, lane);
+    if (NB % 8 != 0 && wave < NB % 8) stage_rows(Wt, wrow_bytes, n0, N, kt * ROWB, base + 256 * ROWB, (NB / 8) * 8 + wave, 1, lane);
+  };
+  stage(0, 0);
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool live = m0 + wm * MT * 16 < M;      // wave-uniform
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // tile kt is in LDS for every wave; the other stage is no longer being read
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* xs = smem + (kt & 1) * STAGE;
+    const char* ws = xs + 256 * ROWB;
+    if (!live) continue;               // rows past M: stage and sync only (see v2)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t wf[NT], xf[MT];
+      int ch = ks * 4 + fg;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        int rw = wn * NT * 16 + t * 16 + fr;
+        wf[t] = *reinterpret_cast<const frag_t*>(ws + rw * ROWB + ((ch ^ (rw & 7)) << 4));
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        int rx = wm * MT * 16 + t * 16 + fr;
+        xf[t] = *reinterpret_cast<const frag_t*>(xs + rx * ROWB + ((ch ^ (rx & 7)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int a = 0; a < NT; ++a) acc[a][b] = Ty<I8>::mma(wf[a], xf[b], acc[a][b]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  gemm_epilogue<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, fr, fg, ea);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // v4: the 256 x 256 tile as a PING-PONG of the two wave groups (waves 0-3 = rows 0-127, waves 4-7 = rows 128-255; waves w
 // and w + 4 share a SIMD).  A K-step is cut into four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each:
 //     [ds_read the quadrant's A (8 x b128) and/or B (4 x b128) fragments; 2 LDS-DMA pieces] s_barrier [16 MFMA] s_barrier
@@ -359,19 +426,49 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
                        int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
   const int kbytes = I8 ? K : 2 * K;
   const int nk = kbytes / ROWB;
-  // variant 2 = 256x128 / 3-stage ring, 3 = 256x256 / 128x64 per wave, 4 = 256x256 ping-pong; 0 = auto: the 256x256 tile
-  // (ping-pong) only where it still fills the chip (N >= 4096), else variant 2.
+  // variant 2 = 256x128 / 3-stage ring, 3 = 256x256 (128x64 per wave), 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;
+  // 0 = auto: the shape with the smallest   rounds(on 256 CUs) x columns x per-flop cost   (v2's 64x64 wave tile costs ~15 %
+  // more per flop than the 128-row ones; a tile count below the CU count is one round of whatever fills most CUs).
   int variant = g_gemm_variant;
-  if (variant != 2 && variant != 3 && variant != 4) variant = (N >= 4096 && M >= 2048) ? 3 : 2;
+  if (variant < 2 || variant > 6) {
+    const int ntm_ = (M + 255) / 256;
+    auto cost = [&](int bn, double eff) {
+      long tiles = (long)ntm_ * ((N + bn - 1) / bn);
+      double rounds = tiles <= 256 ? 1.0 + (256 - tiles) / 256.0 * 0.6 : (double)((tiles + 255) / 256);   // under-filled: idle CUs
+      return rounds * bn * eff;
+    };
+    double c2 = cost(128, 1.15), c3 = cost(256, 1.0), c5 = cost(192, 1.03), c6 = cost(224, 1.03);
+    variant = 2;
+    double best = c2;
+    if (M >= 2048 && N >= 1024) {
+      if (c3 < best) { best = c3; variant = 3; }
+      if (c5 < best) { best = c5; variant = 5; }
+      if (c6 < best) { best = c6; variant = 6; }
+    }
+  }
   const bool v4 = (variant == 4);
   const bool v3 = (variant == 3) || v4;      // same tile and LDS footprint
-  int bm = v3 ? V3_BM : V2_BM, bn = v3 ? V3_BN : BN;
+  const bool v5 = (variant == 5), v6 = (variant == 6);
+  int bm = (v3 || v5 || v6) ? 256 : V2_BM, bn = v3 ? V3_BN : v5 ? 192 : v6 ? 224 : BN;
   int ntm = (M + bm - 1) / bm, ntn = (N + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
-  size_t lds = v3 ? 2 * V3_STAGE : 3 * V2_STAGE;
+  size_t lds = v3 ? 2 * V3_STAGE : (v5 || v6) ? 2 * (size_t)(256 + bn) * ROWB : 3 * V2_STAGE;
 #define LAUNCH(E)                                                                                                      \
   do {                                                                                                                 \
-    if (v4) {                                                                                                          \
+    if (v5 || v6) {                                                                                                    \
+      static bool a5 = false;                                                                                          \
+      if (!a5) {                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<E, I8, 2, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * ROWB); \
+        (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<E, I8, 4, 2, 4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 224) * ROWB); \
+        a5 = true;                                                                                                     \
+      }                                                                                                                \
+      if (v5)                                                                                                          \
+        hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 2, 4, 8, 3>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                 \
+      else                                                                                                             \
+        hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 4, 2, 4, 7>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                 \
+    } else if (v4) {                                                                                                   \
       static bool a4 = false;                                                                                          \
       if (!a4) {                                                                                                       \
         (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
   int iters = argc > 2 ? atoi(argv[2]) : 20;
   bool all = !strcmp(what, "all");
   if (all || !strcmp(what, "gemm")) {
-   for (int variant = 2; variant <= 4; ++variant) {
+   for (int variant = 2; variant <= 6; ++variant) {
     LL(ll_set_tuning("gemm_variant", variant));
     printf("-- gemm_variant %d\n", variant);
     bench_gemm("qkv", 4680, 4608, 1536, LL_EPI_BIAS, iters);
