@@ -42,7 +42,10 @@ enum ll_epilogue {
 
 int ll_version(void);
 const char* ll_last_error(void);
-/* Development knob for A/B timing of kernel variants (tools/kbench); the defaults are the shipped configuration. */
+/* Development knob for A/B timing of kernel variants (tools/kbench, tools/kenergy, LL_TUNING=key=value,... for bench.py);
+ * the defaults are the shipped configuration.  Keys: "gemm_variant" 0 = auto (cost model), 2 = 256x128, 3 = 256x256,
+ * 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;  "attn_variant" 0 = simple, 1 = software-pipelined, 2 = + ping-pong wave
+ * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on.  Unknown key: LL_ERR_INVALID_ARG. */
 int ll_set_tuning(const char* key, int value);
 
 /* ---- norms / modulation ------------------------------------------------------------------------------------- */
