@@ -3,6 +3,8 @@
   config 3: 60-s single-prompt generation (T = 240 latent frames, sliding KV cache + frame sink)
   config 4: interactive multi-prompt stream (T = 240, 6 prompts, switches at 40,80,120,160,200, global_sink = false:
             configs/longlive_interactive_inference.yaml:21-27) exercising KV-recache on every switch.
+  config 5: `960 --quant int8 --only single`: 240-s generation (T = 960, RoPE frame index < 1024) with W8A8 block linears,
+            one replica of the 8 that BASELINE config 5 runs side by side (replicas share nothing: bench.py --gpus 8)
   e2e     : with `--vae`, the same single-prompt stream with every block decoded live by the HIP VAE decoder
             (pipeline.stream_video): generated pixel frames/s including the decode, and the latency of each block's frames.
 Random-init LongLive-1.3B / Wan-VAE weights, synthetic prompt embeddings / noise (longlive_amd.synth)."""
@@ -35,10 +37,14 @@ def main():
     cfg = synth.longlive_1_3b(local_attn_size=12, sink_size=3)
     gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=dev,
                               state_dict=synth.synth_state_dict(cfg, seed=0, device=dev))
+    quant = "int8" if "int8" in sys.argv else None
+    if quant:
+        gen.model.set_quant(quant)
+    only_single = "single" in sys.argv
     prompts = {f"p{i}": {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + i, device=dev)} for i in range(6)}
     enc = lambda text_prompts: prompts[text_prompts[0]]
     noise = synth.synth_noise(cfg, T, seed=0, device=dev)
-    out = {"T_latent": T, "pixel_frames": 4 * T}
+    out = {"T_latent": T, "pixel_frames": 4 * T, "quant": quant or "bf16"}
 
     P = CausalInferencePipeline(args(True), dev, generator=gen, text_encoder=enc)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -51,6 +57,9 @@ def main():
         "finite": bool(torch.isfinite(lat.float()).all()), "latent_std": float(lat.float().std()),
         "end_indices": [P.kv_cache1[0]["global_end_index"], P.kv_cache1[0]["local_end_index"]]}
 
+    if only_single:
+        print(json.dumps(out))
+        return
     sw = [s for s in (40, 80, 120, 160, 200) if s < T]
     I = InteractiveCausalInferencePipeline(args(False), dev, generator=gen, text_encoder=enc)
     torch.cuda.synchronize(); t0 = time.perf_counter()
