@@ -12,11 +12,21 @@ block is a steady-state block with Lk = 18720, roll + insert -- the regime of th
 most expensive one), then exactly K blocks are timed between barrier + device sync on both sides.
 
 Multi-GPU = independent replicas (the path does not shard): every rank generates its own stream
-(own seed / prompt), no data-path collective; value = frames of all ranks / max-over-ranks time.
+(own seed / prompt, inference.py:49,146), no data-path collective, no RCCL; value = frames of all replicas / max-over-replicas
+time.  Two ways to get N replicas:
+  * under torch.distributed.run (the driver's launch): RANK / LOCAL_RANK / WORLD_SIZE from the env; the start/stop barrier
+    and the scalar MAX / SUM go through a gloo (CPU) process group -- nothing touches xGMI;
+  * plain `python bench.py --gpus N` (WORLD_SIZE unset): this process starts N fresh children BEFORE it touches the GPU
+    (HIP_VISIBLE_DEVICES = r, seed + r), synchronises their timed regions over pipes (no process group at all) and prints
+    the one JSON line itself, with per-replica frames/s.  A child that fails => non-zero exit, no retry.
 
 The JSON line also carries
-  roofline     : the dominant kernel (self-attention flash kernel), timed live with HIP events on its launch stream over
-                 the timed region; achieved = algorithmic FLOPs (4 * Lq * Lk * 128 * heads) / avg launch duration
+  roofline     : the dominant kernel (self-attention), timed live with HIP events on its launch stream over the timed
+                 region; achieved = algorithmic FLOPs (4 * Lq * Lk * 128 * heads) / avg launch duration
+  kernels      : per-kernel table of one more (untimed) steady-state block with EVERY launch bracketed by HIP events:
+                 avg us, algorithmic work, achieved, peak, fraction (MFMA kernels against 2.5 PFLOP/s, row kernels against 8 TB/s)
+  extras       : side numbers measured after the timed region (bounded): INT8 frames/s on the same workload, prompt-switch
+                 (recache) latency, VAE decode frames/s, umT5 ms per prompt -- none of them is part of `value`
   cpu_baseline : the CPU oracle (a port of the reference's PyTorch path, oracle/) timed on this host on a bounded sample.
 """
 from __future__ import annotations
@@ -24,6 +34,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -35,26 +46,35 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_I8_DENSE_PEAK_TOPS = 5000.0          # 2x the bf16 rate (v_mfma_i32_16x16x64_i8)
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 PIXEL_FRAMES_PER_LATENT = 4               # VAE temporal stride (wan/configs/wan_t2v_1_3B.py:17)
 BASELINE_FPS = None                       # BASELINE.json "published": {} -> no number for this exact metric on MI355X
+METRIC = "generated frames/sec (832x480) LongLive-1.3B, frame-sink + short-window attention, 4 denoise steps + clean-context pass"
+WORKLOAD = ("LongLive-1.3B 832x480 (latent 16x60x104), 3-frame AR blocks at steady state: Lq=4680, Lk=18720 (sink 3 + window "
+            "12 frames), 5 DiT forwards/block, 30 layers, random-init weights")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=7, help="timed AR blocks (7 blocks = one 5-second clip)")
     ap.add_argument("--warmup", type=int, default=4, help="untimed AR blocks (4 fill the 12-frame window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kernels table and the side numbers after the timed region")
     ap.add_argument("--cpu-layers", type=int, default=2, help="layers of one steady-state forward timed on the CPU")
     ap.add_argument("--workload", choices=["dit", "vae", "t5"], default="dit",
                     help="dit (default): the headline metric.  vae / t5: the section-8f rows (VAE decoder, umT5 encoder) with "
                          "their own roofline and cpu_baseline objects; single GPU, not the driver's metric")
     ap.add_argument("--quant", choices=["none", "int8"], default="none",
                     help="int8: W8A8 block linears (BASELINE config 5); the headline metric is the default bf16 path")
-    return ap.parse_args()
+    ap.add_argument("--stub-workload", action="store_true",
+                    help=argparse.SUPPRESS)      # tests only: replaces the GPU body by a sleep (launcher / rank plumbing on CPU)
+    return ap.parse_args(argv)
 
 
+# ---- CPU baselines (the only place outside tests/ and smoke() that may run the oracle) --------------------------------
 def cpu_baseline(num_layers_sample: int):
     """Times the CPU oracle on `num_layers_sample` of the 30 layers of ONE steady-state DiT forward (L = 4680 query
     tokens, full 18720-slot KV cache, roll + insert) and extrapolates to a block (x 30/sample layers x 5 forwards)."""
@@ -87,8 +107,7 @@ def cpu_baseline(num_layers_sample: int):
     block = 5.0 * fwd
     return dict(value=3 * PIXEL_FRAMES_PER_LATENT / block, unit="frames/s", cores=threads, kind="port",
                 sample=f"{num_layers_sample} of 30 layers of one steady-state DiT forward (L=4680, Lk=18720) in "
-                       f"{dt:.2f}s on {threads} threads, x{30 // num_layers_sample if 30 % num_layers_sample == 0 else 30 / num_layers_sample:.0f} "
-                       f"layers x5 forwards per 12-frame block")
+                       f"{dt:.2f}s on {threads} threads, x{30 / num_layers_sample:.0f} layers x5 forwards per 12-frame block")
 
 
 def cpu_baseline_vae(vae, lat):
@@ -137,110 +156,411 @@ def side_workload(args):
     print(json.dumps(rec), flush=True)
 
 
-def main():
-    args = parse()
-    if args.workload != "dit":
-        return side_workload(args)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+# ---- replica synchronisation -------------------------------------------------------------------------------------------
+class NoSync:
+    """One replica."""
+    world = 1
+
+    def barrier(self):
+        pass
+
+    end_barrier = barrier
+
+    def gather(self, frames, elapsed):
+        return [dict(rank=0, frames=frames, elapsed=elapsed)]
+
+
+class GlooSync:
+    """Under torch.distributed.run: barrier and scalar exchange over a gloo (CPU) group -- the data path has no collective
+    and the timing plumbing does not need the GPUs' interconnect either."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def barrier(self):
+        self.dist.barrier()
+
+    end_barrier = barrier
+
+    def gather(self, frames, elapsed):
+        t = torch.zeros(self.world, 2, dtype=torch.float64)
+        t[self.rank, 0], t[self.rank, 1] = frames, elapsed
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [dict(rank=r, frames=float(t[r, 0]), elapsed=float(t[r, 1])) for r in range(self.world)]
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class PipeSync:
+    """Child of `python bench.py --gpus N`: the parent is the rendezvous.  '@READY' up, 'GO' down = the start barrier; the
+    stop barrier is the parent's max over the children's elapsed times."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def barrier(self):
+        print("@READY", flush=True)
+        line = sys.stdin.readline()
+        if line.strip() != "GO":
+            raise SystemExit(f"replica {self.rank}: launcher went away ({line!r})")
+
+    def end_barrier(self):
+        pass                 # the parent takes the max over the replicas' own elapsed times
+
+    def gather(self, frames, elapsed):
+        return [dict(rank=self.rank, frames=frames, elapsed=elapsed)]
+
+
+# ---- the measured body -------------------------------------------------------------------------------------------------
+def _pipe_args():
+    return SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
+                           context_noise=0, global_sink=True)
+
+
+def _plan_text(fn, *a):
+    import ctypes as C
+    from longlive_amd import _lib
+    buf = C.create_string_buffer(256)
+    _lib.check(fn(*a, buf, 256), "plan")
+    return buf.value.decode()
+
+
+def kernel_table(summary, quant):
+    """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac)."""
+    from longlive_amd import _lib
+    lib = _lib.load()
+    i8 = 1 if quant == "int8" else 0
+    L, C, F1, LK = 4680, 1536, 8960, 18720
+    gemm_shapes = {"gemm_qkv": (L, 3 * C, C), "gemm_o": (L, C, C), "gemm_cq": (L, C, C), "gemm_co": (L, C, C),
+                   "gemm_f1": (L, F1, C), "gemm_f2": (L, C, F1)}
+    what = {"gemm_qkv": "self-attn QKV", "gemm_o": "self-attn O + gate-residual", "gemm_cq": "cross-attn Q",
+            "gemm_co": "cross-attn O + residual", "gemm_f1": "FFN1 + GELU", "gemm_f2": "FFN2 + gate-residual",
+            "flash_attn_self": "self-attention (sink + window from the KV cache)", "flash_attn_cross": "cross-attention (512 text keys)",
+            "ln_modulate": "LayerNorm + modulate (norm1 / norm2 / head)", "layernorm_affine": "norm3",
+            "rmsnorm": "cross-attn q RMSNorm", "qk_norm_rope_kv_store": "q/k RMSNorm + RoPE + KV insert",
+            "kv_roll": "KV window roll", "quantize_rows": "per-token int8 quantisation", "gemm": "embeddings / head GEMMs"}
+    rows = []
+    for tag, s in sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"]):
+        mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
+        if tag in gemm_shapes:
+            name = _plan_text(lib.ll_gemm_plan, *gemm_shapes[tag], i8)
+        elif tag == "flash_attn_self":
+            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1)
+        elif tag == "flash_attn_cross":
+            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1)
+        else:
+            name = {"ln_modulate": "ln_modulate_kernel", "layernorm_affine": "layernorm_affine_kernel", "rmsnorm": "rmsnorm_kernel",
+                    "qk_norm_rope_kv_store": "qk_norm_rope_kv_kernel", "kv_roll": "copy_rows_kernel",
+                    "quantize_rows": "quantize_rows_kernel"}.get(tag, tag)
+        secs = s["avg_ms"] * 1e-3
+        if mfma:
+            peak = MFMA_I8_DENSE_PEAK_TOPS if (i8 and tag in gemm_shapes) else MFMA_BF16_DENSE_PEAK_TFLOPS
+            ach = s["work_per_launch"] / secs / 1e12
+            unit = "TOP/s" if (i8 and tag in gemm_shapes) else "TFLOP/s"
+            bound = "mfma"
+        else:
+            peak, ach, unit, bound = HBM_PEAK_GBS, s["work_per_launch"] / secs / 1e9, "GB/s", "hbm"
+        rows.append({"tag": tag, "what": what.get(tag, tag), "kernel": name, "bound": bound, "launches": s["launches"],
+                     "avg_us": 1e3 * s["avg_ms"], "total_ms": s["total_ms"], "work_per_launch": s["work_per_launch"],
+                     "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
+    return rows
+
+
+def run_extras(gen, pipe_cls, interactive_cls, cfg, dev, budget_s=60.0):
+    """Side numbers after the timed region (never part of `value`), each with its own achieved / peak where one applies."""
+    from longlive_amd import ops, synth
+    t_start = time.perf_counter()
+    ex = {}
+
+    def left():
+        return budget_s - (time.perf_counter() - t_start)
+
+    def fps_of(quant, blocks=4):
+        gen.model.set_quant(quant)
+        pipe = pipe_cls(_pipe_args(), dev, generator=gen)
+        noise = synth.synth_noise(cfg, 3 * (4 + blocks), seed=0, device=dev)
+        st = pipe.stream(noise, {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1, device=dev)})
+        for _ in range(4):
+            next(st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(blocks):
+            next(st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return 12 * blocks / dt, 1e3 * dt / blocks
+
+    try:                                                     # BASELINE config 5's arithmetic on the headline workload
+        fps, ms = fps_of("int8")
+        ex["int8_w8a8"] = {"value": fps, "unit": "frames/s", "ms_per_step": ms,
+                           "workload": "same steady-state blocks, W8A8 block linears (QKV, O, cross-q, cross-o, FFN1, FFN2), bf16 attention"}
+    except Exception as exc:
+        ex["int8_w8a8"] = {"error": repr(exc)}
+    finally:
+        gen.model.set_quant(None)
+
+    try:                                                     # config 4: prompt switch = recache of the 12-frame window
+        I = interactive_cls(_pipe_args(), dev, generator=gen)
+        I.global_sink = False
+        T = 24
+        noise = synth.synth_noise(cfg, T, seed=0, device=dev)
+        prompts = [{"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + i, device=dev)} for i in range(2)]
+        I._setup(noise, T)
+        fs = cfg.frame_seqlen
+        for c in I.kv_cache1:                                # state of a stream 24 frames in: window full
+            c["k"].normal_(); c["v"].normal_()
+            c["global_end_index"], c["local_end_index"] = T * fs, 12 * fs
+            c.pop("_ll_idx", None)
+        lat = []
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            I._recache_after_switch(noise, T, prompts[rep % 2])
+            torch.cuda.synchronize()
+            lat.append(1e3 * (time.perf_counter() - t0))
+        ms = min(lat[1:])
+        flop = 30 * 3772.5e9                                 # SURVEY.md section 8d: GEMM 1560.5 + attn 2153.1 + cross 58.9 GFLOP per layer
+        ex["prompt_switch_latency"] = {"value": ms, "unit": "ms", "higher_is_better": False,
+                                       "what": "InteractiveCausalInferencePipeline._recache_after_switch: 12 frames in ONE forward, L = Lk = 18720, "
+                                               "global_sink=false (kv_only: the last layer stops after its K/V insert)",
+                                       "achieved": flop / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit_rate": "TFLOP/s",
+                                       "frac": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS}
+        del I
+    except Exception as exc:
+        ex["prompt_switch_latency"] = {"error": repr(exc)}
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if left() > 20:
+        try:
+            import vae_bench
+            rec, vae, lat = vae_bench.run(7, 2)
+            ex["vae_decode"] = {"value": rec["pixel_fps"], "unit": "pixel frames/s", "ms_per_latent_frame": rec["ms_per_latent_frame"],
+                                "achieved": rec["roofline"]["achieved"], "peak": rec["roofline"]["peak"], "unit_rate": "TFLOP/s",
+                                "frac": rec["roofline"]["frac"], "what": "streaming Wan-VAE decode 60x104 -> 480x832, all conv launches"}
+            del vae, lat
+        except Exception as exc:
+            ex["vae_decode"] = {"error": repr(exc)}
+    if left() > 25:
+        try:
+            import t5_bench
+            rec = t5_bench.run(3)[0]
+            ex["umt5_encode"] = {"value": rec["ms_per_prompt"], "unit": "ms per prompt", "higher_is_better": False,
+                                 "achieved": rec["tflops"], "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit_rate": "TFLOP/s",
+                                 "frac": rec["roofline"]["frac"], "what": "umT5-xxl encoder, 24 layers, 512 positions"}
+        except Exception as exc:
+            ex["umt5_encode"] = {"error": repr(exc)}
+    ex["seconds"] = time.perf_counter() - t_start
+    torch.cuda.empty_cache()
+    return ex
+
+
+def run_replica(args, rank, world, local_rank, sync):
+    """One replica's timed region.  Returns (record for rank 0 or None)."""
+    if args.stub_workload:                                   # tests: launcher / rank plumbing without a GPU
+        sync.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.05 * (rank + 1))
+        sync.end_barrier()
+        elapsed = time.perf_counter() - t0
+        return dict(frames=args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed=elapsed, roofline=None, kernels=None,
+                    extras=None, cpu_baseline=None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
-    from longlive_amd import ops, synth
-    from longlive_amd.pipeline import CausalInferencePipeline
+    from longlive_amd import _lib, ops, synth
+    from longlive_amd.pipeline import CausalInferencePipeline, InteractiveCausalInferencePipeline
     from longlive_amd.wan_wrapper import WanDiffusionWrapper
 
     for kv in filter(None, os.environ.get("LL_TUNING", "").split(",")):   # kernel A/B only, e.g. LL_TUNING=attn_variant=2
-        from longlive_amd import _lib
         k, v = kv.split("=")
         _lib.check(_lib.load().ll_set_tuning(k.encode(), int(v)), "ll_set_tuning")
     cfg = synth.longlive_1_3b(local_attn_size=12, sink_size=3)
     sd = synth.synth_state_dict(cfg, seed=0, device=dev)               # random-init weights of the 1.3B architecture
     gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=dev, state_dict=sd)
     del sd
-    if args.quant == "int8":
-        gen.model.set_quant("int8")
-    pargs = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
-                            denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
-                            context_noise=0, global_sink=True)
-    pipe = CausalInferencePipeline(pargs, dev, generator=gen)
-    nblocks = args.warmup + args.steps
+    quant = None if args.quant == "none" else args.quant
+    gen.model.set_quant(quant)
+    pipe = CausalInferencePipeline(_pipe_args(), dev, generator=gen)
+    extra_blocks = 0 if (args.no_extras or rank != 0) else 1           # one more steady-state block for the kernels table
+    nblocks = args.warmup + args.steps + extra_blocks
     T = 3 * nblocks
     assert T <= 1024, "RoPE frame table has 1024 entries"
-    # one independent stream per rank (inference.py:49,146: seed + rank, prompts sharded by rank)
+    # one independent stream per replica (inference.py:49,146: seed + rank, prompts sharded by rank)
     noise = synth.synth_noise(cfg, T, seed=rank, device=dev)
     prompt = {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + rank, device=dev)}
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     stream = pipe.stream(noise, prompt)
     for _ in range(args.warmup):
         next(stream)
     ktimer = None
-    if not args.no_kernel_timer:
+    if not args.no_kernel_timer and rank == 0:
         ktimer = ops.KernelTimer(tags=("flash_attn_self",))
-    barrier()
+    torch.cuda.synchronize()
+    sync.barrier()
+    torch.cuda.synchronize()
     ops.timer = ktimer
     t0 = time.perf_counter()
     for _ in range(args.steps):
         next(stream)
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
+    sync.end_barrier()
     elapsed = time.perf_counter() - t0
     ops.timer = None
-    from longlive_amd.replicas import aggregate_throughput
-    frames, elapsed = aggregate_throughput(args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed, device=dev)
-    fps = frames / elapsed
-    out = {
-        "metric": "generated frames/sec (832x480) LongLive-1.3B, frame-sink + short-window attention, 4 denoise steps + clean-context pass",
-        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": (fps / BASELINE_FPS) if BASELINE_FPS else None,
-        "dtype": "bf16" if args.quant == "none" else "int8 (W8A8 block linears, bf16 attention/norms)", "data": "synthetic",
-        "config": {"workload": "LongLive-1.3B 832x480 (latent 16x60x104), 3-frame AR blocks at steady state: "
-                               "Lq=4680, Lk=18720 (sink 3 + window 12 frames), 5 DiT forwards/block, 30 layers, random-init weights",
-                   "frames_per_step": 3 * PIXEL_FRAMES_PER_LATENT, "ms_per_latent_frame": 1e3 * elapsed / args.steps / 3,
-                   "replicas": world, "parallelism": f"replicas x{world} (no collective on the data path)"},
-    }
-    if rank == 0:
-        roof = None
-        if ktimer is not None and "flash_attn_self" in ktimer.records:
-            s = ktimer.summary()["flash_attn_self"]
-            achieved = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "attn_pmc.json")
+    res = dict(frames=args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed=elapsed, roofline=None, kernels=None, extras=None,
+               cpu_baseline=None)
+    if rank != 0:
+        return res
+    if ktimer is not None and "flash_attn_self" in ktimer.records:
+        s = ktimer.summary()["flash_attn_self"]
+        achieved = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
+        traffic, src = None, None
+        for name in ("r02_attn_pmc.json", "attn_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 try:
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    src = (f"profiles/{name}: rocprofv3 --pmc passes over tools/kbench on the same kernel and shape "
+                           "(TCC_EA0_RDREQ/WRREQ, gfx950 x2 read correction); NOT measured in this run")
+                    break
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "flash_attn_pipe_kernel<8, 1> (self-attention, ping-pong wave groups, Lq=4680, Lk=18720, 12 heads)", "achieved": achieved,
-                    "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                    "traffic": traffic, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
-                    "flop_per_launch": s["work_per_launch"],
-                    "share_of_step": s["total_ms"] / (1e3 * elapsed)}
-        out["roofline"] = roof
-        out["cpu_baseline"] = None
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_layers)
-            except Exception as exc:      # the baseline is reporting only; never lose the GPU number over it
-                out["cpu_baseline"] = {"error": repr(exc)}
-        print(json.dumps(out), flush=True)
-    if distributed:
-        dist.destroy_process_group()
+        res["roofline"] = {"bound": "mfma", "kernel": _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1)
+                           + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,
+                           "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                           "traffic": traffic, "traffic_source": src, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
+                           "flop_per_launch": s["work_per_launch"], "share_of_step": s["total_ms"] / (1e3 * elapsed)}
+    if extra_blocks:
+        try:
+            ops.timer = ops.KernelTimer()                              # every tagged launch of one more steady-state block
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            next(stream)
+            torch.cuda.synchronize()
+            blk_ms = 1e3 * (time.perf_counter() - t0)
+            summ = ops.timer.summary()
+            ops.timer = None
+            rows = kernel_table(summ, quant)
+            res["kernels"] = {"note": "one untimed steady-state block, HIP events around every launch (adds ~2 us of gap per launch: "
+                                      f"this block took {blk_ms:.1f} ms); shares are of the sum of kernel time",
+                              "sum_kernel_ms": sum(r["total_ms"] for r in rows), "rows": rows}
+        except Exception as exc:
+            ops.timer = None
+            res["kernels"] = {"error": repr(exc)}
+        del stream, pipe
+        try:
+            res["extras"] = run_extras(gen, CausalInferencePipeline, InteractiveCausalInferencePipeline, cfg, dev)
+        except Exception as exc:
+            res["extras"] = {"error": repr(exc)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_layers)
+        except Exception as exc:      # the baseline is reporting only; never lose the GPU number over it
+            res["cpu_baseline"] = {"error": repr(exc)}
+    return res
+
+
+def final_record(args, world, per_replica, res0):
+    frames = sum(r["frames"] for r in per_replica)
+    elapsed = max(r["elapsed"] for r in per_replica)
+    fps = frames / elapsed
+    out = {
+        "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": (fps / BASELINE_FPS) if BASELINE_FPS else None,
+        "dtype": "bf16" if args.quant == "none" else "int8 (W8A8 block linears, bf16 attention/norms)", "data": "synthetic",
+        "config": {"workload": WORKLOAD, "frames_per_step": 3 * PIXEL_FRAMES_PER_LATENT,
+                   "ms_per_latent_frame": 1e3 * elapsed / args.steps / 3, "replicas": world,
+                   "parallelism": f"replicas x{world} (no collective on the data path, no RCCL)",
+                   "per_replica_fps": [r["frames"] / r["elapsed"] for r in sorted(per_replica, key=lambda r: r["rank"])]},
+        "roofline": res0.get("roofline"), "cpu_baseline": res0.get("cpu_baseline"),
+    }
+    if res0.get("kernels") is not None:
+        out["kernels"] = res0["kernels"]
+    if res0.get("extras") is not None:
+        out["extras"] = res0["extras"]
+    return out
+
+
+# ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
+def launch_replicas(args, argv):
+    """Starts N children before this process has touched the GPU (no torch.cuda call above this line in the parent), one
+    device each, and acts as their rendezvous.  No retry: any child failure ends the run with a non-zero exit."""
+    n = args.gpus
+    if not args.stub_workload:
+        ndev = torch.cuda.device_count()                       # counting devices does not initialise HIP on this image
+        if ndev < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(LL_BENCH_CHILD="1", LL_BENCH_RANK=str(r), LL_BENCH_WORLD=str(n), HIP_VISIBLE_DEVICES=str(r),
+                   HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.pop("ROCR_VISIBLE_DEVICES", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def fail(msg):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit(f"bench.py launcher: {msg}")
+
+    def read_until(p, r, prefix):
+        while True:
+            line = p.stdout.readline()
+            if line == "":
+                fail(f"replica {r} exited (code {p.wait()}) before '{prefix}'")
+            if line.startswith(prefix):
+                return line[len(prefix):].strip()
+            sys.stderr.write(f"[replica {r}] {line}")
+
+    for r, p in enumerate(procs):
+        read_until(p, r, "@READY")
+    for p in procs:                                               # start barrier: every replica is warmed up and synced
+        p.stdin.write("GO\n")
+        p.stdin.flush()
+    results = [json.loads(read_until(p, r, "@RESULT")) for r, p in enumerate(procs)]
+    for r, p in enumerate(procs):
+        p.stdin.close()
+        if p.wait() != 0:
+            fail(f"replica {r} exited with code {p.returncode}")
+    per = [dict(rank=r, frames=res["frames"], elapsed=res["elapsed"]) for r, res in enumerate(results)]
+    print(json.dumps(final_record(args, n, per, results[0])), flush=True)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.workload != "dit":
+        return side_workload(args)
+    if os.environ.get("LL_BENCH_CHILD") == "1":                   # a replica started by launch_replicas
+        rank, world = int(os.environ["LL_BENCH_RANK"]), int(os.environ["LL_BENCH_WORLD"])
+        res = run_replica(args, rank, world, 0, PipeSync(rank, world))
+        print("@RESULT " + json.dumps(res), flush=True)
+        return
+    if "WORLD_SIZE" in os.environ:                                # torch.distributed.run
+        rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+        sync = GlooSync(rank, world) if world > 1 else NoSync()
+        res = run_replica(args, rank, world, local_rank, sync)
+        per = sync.gather(res["frames"], res["elapsed"])
+        if rank == 0:
+            print(json.dumps(final_record(args, world, per, res)), flush=True)
+        if world > 1:
+            sync.close()
+        return
+    if args.gpus > 1:
+        return launch_replicas(args, argv)
+    res = run_replica(args, 0, 1, 0, NoSync())
+    print(json.dumps(final_record(args, 1, [dict(rank=0, frames=res["frames"], elapsed=res["elapsed"])], res)), flush=True)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,10 @@ const char* ll_last_error(void);
  * 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;  "attn_variant" 0 = simple, 1 = software-pipelined, 2 = + ping-pong wave
  * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on.  Unknown key: LL_ERR_INVALID_ARG. */
 int ll_set_tuning(const char* key, int value);
+/* Host-only introspection: the kernel instance + tile + grid that ll_gemm_bf16 / ll_gemm_w8a8 / ll_flash_attn would launch
+ * for a shape under the current tuning, as text in out[cap] (bench.py's per-kernel table names kernels from here). */
+int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap);
+int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, char* out, int cap);
 
 /* ---- norms / modulation ------------------------------------------------------------------------------------- */
 

@@ -18,6 +18,8 @@ SIGNATURES = {
     "ll_version": [],
     "ll_last_error": [],
     "ll_set_tuning": [C.c_char_p, _i],
+    "ll_gemm_plan": [_i, _i, _i, _i, C.c_char_p, _i],
+    "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, C.c_char_p, _i],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ll_ln_modulate_q8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],

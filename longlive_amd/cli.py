@@ -140,20 +140,12 @@ def model_type_of(config, lora_enabled: bool) -> str:
 
 # ---- video files -------------------------------------------------------------------------------------------------------
 def write_avi_rgb24(path: str, frames: torch.Tensor, fps: int = 16) -> None:
-    """Uncompressed AVI (RIFF, one 'vids' stream of bottom-up BGR24 DIBs + idx1).  frames uint8 [T, H, W, 3] RGB."""
+    """Uncompressed AVI (RIFF, one 'vids' stream of bottom-up BGR24 DIBs + idx1).  frames uint8 [T, H, W, 3] RGB.
+    Streamed to disk one frame at a time: all sizes are known up front, so a 3840-frame clip never exists twice in memory."""
     assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3
     T, H, W, _ = frames.shape
     stride = (W * 3 + 3) & ~3
     fsz = stride * H
-    data = frames.flip(1).flip(-1).contiguous().numpy()             # bottom-up rows, BGR
-    chunks = []
-    for t in range(T):
-        rows = data[t].reshape(H, W * 3)
-        if stride != W * 3:
-            import numpy as np
-            rows = np.concatenate([rows, np.zeros((H, stride - W * 3), dtype=np.uint8)], 1)
-        chunks.append(b"00db" + struct.pack("<I", fsz) + rows.tobytes())
-    movi = b"movi" + b"".join(chunks)
     avih = struct.pack("<IIIIIIIIII4I", 1000000 // fps, fsz * fps, 0, 0x10, T, 0, 1, fsz, W, H, 0, 0, 0, 0)
     strh = struct.pack("<4s4sIHHIIIIIIII4H", b"vids", b"DIB ", 0, 0, 0, 0, 1, fps, 0, T, fsz, 0xFFFFFFFF, 0, 0, 0, W, H)
     strf = struct.pack("<IiiHHIIiiII", 40, W, H, 1, 24, 0, fsz, 0, 0, 0, 0)
@@ -166,13 +158,25 @@ def write_avi_rgb24(path: str, frames: torch.Tensor, fps: int = 16) -> None:
 
     strl = lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf))
     hdrl = lst(b"hdrl", chunk(b"avih", avih) + strl)
-    idx, off = b"", 4
-    for t in range(T):
-        idx += b"00db" + struct.pack("<III", 0x10, off, fsz)
-        off += 8 + fsz
-    body = hdrl + b"LIST" + struct.pack("<I", len(movi)) + movi + chunk(b"idx1", idx)
+    movi_len = 4 + T * (8 + fsz)                                    # 'movi' + T x ('00db' size data); fsz is even
+    idx_len = 16 * T
+    riff_len = 4 + len(hdrl) + 8 + movi_len + 8 + idx_len
+    pad = bytes(stride - W * 3)
     with open(path, "wb") as f:
-        f.write(b"RIFF" + struct.pack("<I", len(body) + 4) + b"AVI " + body)
+        f.write(b"RIFF" + struct.pack("<I", riff_len) + b"AVI " + hdrl + b"LIST" + struct.pack("<I", movi_len) + b"movi")
+        for t in range(T):
+            rows = frames[t].flip(0).flip(-1).contiguous().numpy().reshape(H, W * 3)      # bottom-up rows, BGR
+            f.write(b"00db" + struct.pack("<I", fsz))
+            if pad:
+                for r in rows:
+                    f.write(r.tobytes() + pad)
+            else:
+                f.write(rows.tobytes())
+        f.write(b"idx1" + struct.pack("<I", idx_len))
+        off = 4
+        for t in range(T):
+            f.write(b"00db" + struct.pack("<III", 0x10, off, fsz))
+            off += 8 + fsz
 
 
 def read_avi_rgb24(path: str) -> torch.Tensor:
@@ -198,12 +202,13 @@ def write_video(path: str, frames: torch.Tensor, fps: int = 16) -> str:
     frames = frames.to(torch.uint8).cpu()
     try:
         from torchvision.io import write_video as tv_write          # noqa: WPS433 (optional dependency)
-        tv_write(path, frames, fps=fps)
-        return path
-    except Exception:                                               # torchvision / av missing: keep the frames anyway
+        import av                                                   # noqa: F401  (what torchvision's writer needs)
+    except ImportError:                                             # torchvision / PyAV missing: keep the frames anyway
         alt = os.path.splitext(path)[0] + ".avi"
         write_avi_rgb24(alt, frames, fps)
         return alt
+    tv_write(path, frames, fps=fps)                                 # real I/O errors propagate
+    return path
 
 
 # ---- tokenizers --------------------------------------------------------------------------------------------------------
@@ -317,8 +322,9 @@ def run(mode: str, config, synthetic: bool = False, device: Optional[torch.devic
         assert len(switch) == nseg - 1, "The number of switch_frame_indices should be the number of prompt segments minus 1"
     else:
         dataset = TextDataset(prompt_path=config.data_path, extended_prompt_path=config.data_path)
-    if local_rank == 0:
-        os.makedirs(config.output_folder, exist_ok=True)
+    # every rank creates the folder: the CLI builds no process group, so there is no barrier to order a rank-0-only
+    # makedirs before the other ranks' first write (the reference has dist.barrier() there, inference.py:153-156)
+    os.makedirs(config.output_folder, exist_ok=True)
     model_type = model_type_of(config, lora_enabled)
     records = []
     for i, idx in enumerate(rank_indices(len(dataset), rank, world)):

@@ -15,6 +15,8 @@
 //                       HBM latency hides under compute) -> XOR-swizzled LDS (double buffered, one barrier per tile).
 //   LDS swizzles: K row = 256 B; 16-B chunk c of key r at position c ^ (r & 15)  -> ds_read_b128 A-fragments conflict-free
 //                 V row = 256 B; 16-B chunk c of key r at position c ^ ((r & 3) << 2) -> tr_b16 reads conflict-free
+#include <stdio.h>
+
 #include "common.h"
 
 #define KT 64                       // keys per tile
@@ -623,6 +625,22 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
                        (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
                        k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
   return ll_check_launch("ll_flash_attn(pipe)");
+}
+
+// Which kernel instance ll_flash_attn launches for these key ranges under the current tuning (host only).
+extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, char* out, int cap) {
+  LL_REQUIRE(out != nullptr && cap > 0, "ll_flash_attn_plan: needs an output buffer");
+  int n0 = seg0_len, n1 = seg1_len;
+  if (n1 > 0 && seg_adjacent) { n0 += n1; n1 = 0; }
+  if (g_attn_variant >= 1 && n1 == 0) {
+    int nqt = (Lq + 255) / 256;
+    bool pp = g_attn_variant >= 2 && n0 >= 16 * KT;
+    snprintf(out, (size_t)cap, "flash_attn_pipe_kernel<8, %d> (%s), %d workgroups of 256 query rows%s", pp ? 1 : 0,
+             pp ? "ping-pong wave groups" : "one-barrier loop", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
+  } else {
+    snprintf(out, (size_t)cap, "flash_attn_kernel<4>, %d workgroups of 128 query rows", ((Lq + 127) / 128) * H * B);
+  }
+  return LL_OK;
 }
 
 extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H,

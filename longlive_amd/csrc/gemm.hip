@@ -18,6 +18,7 @@
 //       ~40% fewer LDS bytes per FLOP (4096^3: 1.00-1.05 PF vs 0.90).
 // (A first 128 x 128 / 4-wave / 2-barrier kernel, ~0.7 PF, was retired; experiments with up-front double fragment sets and
 //  a DMA-issue stagger between the two waves of a SIMD measured 0...-5% and were not kept.)
+#include <stdio.h>
 #include <string.h>
 
 #include "gemm_common.h"
@@ -420,15 +421,10 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const bf16* __restri
   }
 }
 
-// ===============================================================================================================
-template <bool I8>
-static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, int K, size_t xrow_bytes, size_t wrow_bytes,
-                       int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
-  const int kbytes = I8 ? K : 2 * K;
-  const int nk = kbytes / ROWB;
-  // variant 2 = 256x128 / 3-stage ring, 3 = 256x256 (128x64 per wave), 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;
-  // 0 = auto: the shape with the smallest   rounds(on 256 CUs) x columns x per-flop cost   (v2's 64x64 wave tile costs ~15 %
-  // more per flop than the 128-row ones; a tile count below the CU count is one round of whatever fills most CUs).
+// variant 2 = 256x128 / 3-stage ring, 3 = 256x256 (128x64 per wave), 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;
+// 0 = auto: the shape with the smallest   rounds(on 256 CUs) x columns x per-flop cost   (v2's 64x64 wave tile costs ~15 %
+// more per flop than the 128-row ones; a tile count below the CU count is one round of whatever fills most CUs).
+static int pick_gemm_variant(int M, int N) {
   int variant = g_gemm_variant;
   if (variant < 2 || variant > 6) {
     const int ntm_ = (M + 255) / 256;
@@ -446,6 +442,29 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
       if (c6 < best) { best = c6; variant = 6; }
     }
   }
+  return variant;
+}
+
+// Which kernel instance and tile ll_gemm_bf16 / ll_gemm_w8a8 launch for this shape under the current tuning (host only;
+// bench.py's per-kernel table takes its kernel names from here instead of hard-coding them).
+extern "C" int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap) {
+  LL_REQUIRE(out != nullptr && cap > 0, "ll_gemm_plan: needs an output buffer");
+  const int v = pick_gemm_variant(M, N);
+  const int bn = v == 3 || v == 4 ? 256 : v == 5 ? 192 : v == 6 ? 224 : 128;
+  const char* name = v == 2 ? "gemm_kernel_v2" : v == 3 ? "gemm_kernel_v3" : v == 4 ? "gemm_kernel_v4" : "gemm_kernel_v5";
+  int ntm = (M + 255) / 256, ntn = (N + bn - 1) / bn;
+  snprintf(out, (size_t)cap, "%s<%s> tile 256x%d, %d workgroups", name, int8 ? "i8" : "bf16", bn, ntm * ntn);
+  (void)K;
+  return LL_OK;
+}
+
+// ===============================================================================================================
+template <bool I8>
+static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, int K, size_t xrow_bytes, size_t wrow_bytes,
+                       int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
+  const int kbytes = I8 ? K : 2 * K;
+  const int nk = kbytes / ROWB;
+  const int variant = pick_gemm_variant(M, N);
   const bool v4 = (variant == 4);
   const bool v3 = (variant == 3) || v4;      // same tile and LDS footprint
   const bool v5 = (variant == 5), v6 = (variant == 6);

@@ -127,6 +127,9 @@ class CausalWanModelHIP(nn.Module):
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
         self._ctx_cache = None
+        # nn.Module's recursive load (e.g. WanDiffusionWrapper.load_state_dict, as inference.py:87/94 loads) never calls a
+        # child's load_state_dict override, only its _load_from_state_dict -- which runs these hooks.
+        self._register_load_state_dict_pre_hook(self._invalidate_derived)
 
     # ---- parameter packing -------------------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -136,9 +139,18 @@ class CausalWanModelHIP(nn.Module):
         self._ctx_cache = None
         return super()._apply(fn, *a, **k)
 
-    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+    def _invalidate_derived(self, *unused_hook_args):
+        """Drop everything derived from the parameters: the fused QKV / int8 copies and the memoised text embedding."""
         self._packed = None
         self._ctx_cache = None
+
+    def invalidate_packed(self):
+        """Call after writing parameters through `.data` (which bypasses the version counter that `_pack` checks);
+        load_state_dict (direct or through a parent), `.to()` and in-place ops under no_grad are detected automatically."""
+        self._invalidate_derived()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._invalidate_derived()
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     @staticmethod
@@ -147,9 +159,23 @@ class CausalWanModelHIP(nn.Module):
         the KV-cache branch of self-attention never reads it (causal_model.py:205-360).  Kept for call compatibility."""
         return None
 
+    def _param_key(self):
+        """(address, version) of every parameter a packed copy is made from: an in-place update (EMA swap, LoRA re-fold,
+        `param.copy_`) bumps `_version`, a re-assignment changes the address."""
+        key = []
+        for blk in self.blocks:
+            sa = blk.self_attn
+            ts = [sa.q.weight, sa.k.weight, sa.v.weight, sa.q.bias, sa.k.bias, sa.v.bias, blk.modulation]
+            if self.quant == "int8":
+                ts += [sa.o.weight, blk.cross_attn.q.weight, blk.cross_attn.o.weight, blk.ffn[0].weight, blk.ffn[2].weight]
+            key.extend((t.data_ptr(), t._version) for t in ts)
+        return tuple(key)
+
     def _pack(self):
         if self._packed is not None:
-            return self._packed
+            if self._packed_key == self._param_key():
+                return self._packed
+            self._invalidate_derived()
         P = []
         for blk in self.blocks:
             sa, ca = blk.self_attn, blk.cross_attn
@@ -164,7 +190,7 @@ class CausalWanModelHIP(nn.Module):
                     d["q_" + name], d["s_" + name] = ops.quantize_rows(w.detach().contiguous())
             P.append(d)
         self._packed = P
-        self._packed_quant = self.quant
+        self._packed_key = self._param_key()
         return P
 
     def set_quant(self, mode: Optional[str]):
@@ -182,8 +208,8 @@ class CausalWanModelHIP(nn.Module):
         a bf16 tensor (quantised here, per token) or an already quantised (int8, scale) pair from a fused producer."""
         if self.quant == "int8":
             xq, sx = x if isinstance(x, tuple) else ops.quantize_rows(x)
-            return ops.gemm_w8a8(xq, sx, pk["q_" + key], pk["s_" + key], b, epilogue, **kw)
-        return ops.gemm(x, w, b, epilogue, **kw)
+            return ops.gemm_w8a8(xq, sx, pk["q_" + key], pk["s_" + key], b, epilogue, tag="gemm_" + key, **kw)
+        return ops.gemm(x, w, b, epilogue, tag="gemm_" + key, **kw)
 
     def _rope_tables(self, hp: int, wp: int, device):
         """fp32 (cos, sin) tables from the reference's fp64 angles (model.py:29-36; causal_model.py:622-629):
@@ -238,6 +264,69 @@ class CausalWanModelHIP(nn.Module):
         self._ctx_cache = (key[0], key[1], out, context)   # holding `context` keeps its address from being reused
         return out
 
+    # ---- one block ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def block_forward(self, i: int, xs: torch.Tensor, e0: torch.Tensor, ctx: Optional[torch.Tensor], kvc: dict,
+                      cac: dict, F: int, grid_hw: Tuple[int, int], current_start: int,
+                      sink_recache_after_switch: bool = False, q_buf: Optional[torch.Tensor] = None,
+                      kv_insert_only: bool = False, pk: Optional[dict] = None) -> KVPlan:
+        """CausalWanAttentionBlock.forward (causal_model.py:413-477) for block `i`: updates the residual stream
+        xs [B, L, C] IN PLACE (L = F * hp * wp tokens, grid_hw = (hp, wp) tokens per frame) and this layer's KV / cross
+        caches, returns the layer's KV plan (the caller commits the end indices after all layers,
+        causal_model.py:1061-1062).  e0 [B, F, 6, C]; ctx = embedded text [B, 512, C] (only read when the cross cache is
+        not initialised).  kv_insert_only: stop after the K/V insert."""
+        c = self.cfg
+        B, L, C = xs.shape
+        Hh, D = c.num_heads, c.head_dim
+        hp, wp = grid_hw
+        fs = hp * wp
+        if L != F * fs:
+            raise ValueError(f"block_forward: {L} tokens are not {F} frames of {hp}x{wp}")
+        rope_f, rope_hw = self._rope_tables(hp, wp, xs.device)
+        if q_buf is None:
+            q_buf = torch.empty(B, L, Hh, D, dtype=bf16, device=xs.device)
+        blk = self.blocks[i]
+        if pk is None:
+            pk = self._pack()[i]
+        sa, ca = blk.self_attn, blk.cross_attn
+        # --- self attention (causal_model.py:444-456) ---
+        q8 = self.quant == "int8"
+        h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 0, 1, F, c.eps)
+        qkv = self._lin(h1, pk, "qkv", pk["wqkv"], pk["bqkv"])
+        G, E = _kv_state(kvc)
+        S = kvc["k"].shape[1]
+        plan = plan_update(current_start, L, G, E, S, self.sink_size * fs, self.local_attn_size,
+                           sa.max_attention_size, sink_recache_after_switch)
+        if plan.roll is not None:
+            ops.kv_roll(kvc["k"], kvc["v"], *plan.roll)
+        ops.qk_norm_rope_kv_store(qkv, sa.norm_q.weight, sa.norm_k.weight, rope_f, rope_hw, q_buf.view(B, L, C),
+                                  kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
+                                  plan.roped_offset, plan.write_len, c.eps)
+        if kv_insert_only:
+            return plan
+        att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
+        self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
+                  mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
+        # --- cross attention (causal_model.py:460; model.py:159-194) ---
+        xn = (ops.layernorm_affine_q8 if q8 else ops.layernorm_affine)(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
+        qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
+        if not cac["is_init"]:
+            kc = ops.gemm(ctx, ca.k.weight, ca.k.bias)
+            if cac["k"].shape != (B, c.text_len, Hh, D) or not cac["k"].is_contiguous():
+                cac["k"] = torch.empty(B, c.text_len, Hh, D, dtype=bf16, device=xs.device)
+                cac["v"] = torch.empty(B, c.text_len, Hh, D, dtype=bf16, device=xs.device)
+            ops.rmsnorm(kc, ca.norm_k.weight, c.eps, out=cac["k"].view(B, c.text_len, C))
+            ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
+            cac["is_init"] = True
+        atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
+        self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
+        # --- FFN (causal_model.py:462-468) ---
+        h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 3, 4, F, c.eps)
+        ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
+        self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
+                  mod=pk["mod"], gate_idx=5, rows_per_batch=L, frame_len=fs)
+        return plan
+
     # ---- forward -----------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_frames(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, kv_cache: List[dict],
@@ -258,9 +347,6 @@ class CausalWanModelHIP(nn.Module):
         Hh, D, C = c.num_heads, c.head_dim, c.dim
         assert current_start % fs == 0, "current_start must sit on a frame boundary"
         x = x.to(bf16).contiguous()
-        P = self._pack()
-        rope_f, rope_hw = self._rope_tables(hp, wp, x.device)
-
         pe = self.patch_embedding
         xs = ops.gemm(ops.patchify(x), pe.weight.view(C, -1), pe.bias)                      # [B, L, C]
         e, e0 = self.time_embed(t)
@@ -269,46 +355,12 @@ class CausalWanModelHIP(nn.Module):
 
         q_buf = torch.empty(B, L, Hh, D, dtype=bf16, device=x.device)
         plans: List[KVPlan] = []
-        for i, blk in enumerate(self.blocks):
-            pk, kvc, cac = P[i], kv_cache[i], crossattn_cache[i]
-            sa, ca = blk.self_attn, blk.cross_attn
-            # --- self attention (causal_model.py:444-456) ---
-            q8 = self.quant == "int8"
-            h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 0, 1, F, c.eps)
-            qkv = self._lin(h1, pk, "qkv", pk["wqkv"], pk["bqkv"])
-            G, E = _kv_state(kvc)
-            S = kvc["k"].shape[1]
-            plan = plan_update(current_start, L, G, E, S, self.sink_size * fs, self.local_attn_size,
-                               sa.max_attention_size, sink_recache_after_switch)
-            plans.append(plan)
-            if plan.roll is not None:
-                ops.kv_roll(kvc["k"], kvc["v"], *plan.roll)
-            ops.qk_norm_rope_kv_store(qkv, sa.norm_q.weight, sa.norm_k.weight, rope_f, rope_hw, q_buf.view(B, L, C),
-                                      kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
-                                      plan.roped_offset, plan.write_len, c.eps)
-            if kv_only and i == len(self.blocks) - 1:
-                break
-            att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
-            self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                     mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
-            # --- cross attention (causal_model.py:460; model.py:159-194) ---
-            xn = (ops.layernorm_affine_q8 if q8 else ops.layernorm_affine)(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
-            qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
-            if not cac["is_init"]:
-                kc = ops.gemm(ctx, ca.k.weight, ca.k.bias)
-                if cac["k"].shape != (B, c.text_len, Hh, D) or not cac["k"].is_contiguous():
-                    cac["k"] = torch.empty(B, c.text_len, Hh, D, dtype=bf16, device=x.device)
-                    cac["v"] = torch.empty(B, c.text_len, Hh, D, dtype=bf16, device=x.device)
-                ops.rmsnorm(kc, ca.norm_k.weight, c.eps, out=cac["k"].view(B, c.text_len, C))
-                ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
-                cac["is_init"] = True
-            atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
-            self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
-            # --- FFN (causal_model.py:462-468) ---
-            h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 3, 4, F, c.eps)
-            ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
-            self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                     mod=pk["mod"], gate_idx=5, rows_per_batch=L, frame_len=fs)
+        last = len(self.blocks) - 1
+        P = self._pack()       # validated against the live parameters once per forward
+        for i in range(len(self.blocks)):
+            plans.append(self.block_forward(i, xs, e0, ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp), current_start,
+                                            sink_recache_after_switch, q_buf, kv_insert_only=kv_only and i == last,
+                                            pk=P[i]))
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)

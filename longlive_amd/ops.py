@@ -55,6 +55,16 @@ class KernelTimer:
 timer: Optional[KernelTimer] = None
 
 
+def _t0(tag: str):
+    return timer.begin(tag) if timer is not None else None
+
+
+def _t1(tag: str, ev, work: float):
+    """work = the launch's ALGORITHMIC FLOPs (MFMA kernels) or bytes (HBM-bound row kernels), SURVEY.md section 8d."""
+    if timer is not None:
+        timer.end(tag, ev, work)
+
+
 def _chk(t: torch.Tensor, name: str, dtype=bf16) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a device tensor (longlive_amd has no CPU path)")
@@ -69,7 +79,7 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float, out=None):
+def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float, out=None, tag: str = "ln_modulate"):
     """x [B,L,C]; e [B,F,nmod,C]; mod [nmod,C] (causal_model.py:445,463-464,506-507)."""
     _chk(x, "x"); _chk(e, "e"); _chk(mod, "mod")
     B, L, Cc = x.shape
@@ -79,12 +89,14 @@ def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps:
     out = torch.empty_like(x) if out is None else _chk(out, "out")
     assert out.shape == x.shape
     lib = _lib.load()
+    t0 = _t0(tag)
     _lib.check(lib.ll_ln_modulate(x.data_ptr(), out.data_ptr(), e.data_ptr(), mod.data_ptr(), nmod, shift_idx,
                                   scale_idx, B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate")
+    _t1(tag, t0, 4.0 * x.numel())                    # read x, write out (bf16)
     return out
 
 
-def ln_modulate_q8(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float):
+def ln_modulate_q8(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float, tag: str = "ln_modulate"):
     """ln_modulate emitting (int8 [B,L,C], float32 scale [B*L]) for a following W8A8 GEMM."""
     _chk(x, "x"); _chk(e, "e"); _chk(mod, "mod")
     B, L, Cc = x.shape
@@ -93,8 +105,10 @@ def ln_modulate_q8(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, e
     q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
     sc = torch.empty(B * L, dtype=torch.float32, device=x.device)
     lib = _lib.load()
+    t0 = _t0(tag)
     _lib.check(lib.ll_ln_modulate_q8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), e.data_ptr(), mod.data_ptr(), nmod,
                                      shift_idx, scale_idx, B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate_q8")
+    _t1(tag, t0, 3.0 * x.numel())                    # read bf16, write int8
     return q, sc
 
 
@@ -105,8 +119,10 @@ def layernorm_affine_q8(x, w, b, eps: float):
     q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
     sc = torch.empty(rows, dtype=torch.float32, device=x.device)
     lib = _lib.load()
+    t0 = _t0("layernorm_affine")
     _lib.check(lib.ll_layernorm_affine_q8(x.data_ptr(), w.data_ptr(), b.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, Cc,
                                           eps, _stream()), "ll_layernorm_affine_q8")
+    _t1("layernorm_affine", t0, 3.0 * x.numel())
     return q, sc
 
 
@@ -117,8 +133,10 @@ def layernorm_affine(x, w, b, eps: float, out=None):
     out = torch.empty_like(x) if out is None else _chk(out, "out")
     assert out.shape == x.shape
     lib = _lib.load()
+    t0 = _t0("layernorm_affine")
     _lib.check(lib.ll_layernorm_affine(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), x.numel() // Cc, Cc,
                                        eps, _stream()), "ll_layernorm_affine")
+    _t1("layernorm_affine", t0, 4.0 * x.numel())
     return out
 
 
@@ -138,8 +156,10 @@ def rmsnorm(x, w, eps: float, out=None, C: Optional[int] = None):
     o2 = out.flatten(0, -2) if out.dim() > 2 else out
     assert o2.dim() == 2 and o2.data_ptr() == out.data_ptr() and o2.shape[0] == rows and o2.shape[1] >= Cc
     lib = _lib.load()
+    t0 = _t0("rmsnorm")
     _lib.check(lib.ll_rmsnorm(x2.data_ptr(), w.data_ptr(), o2.data_ptr(), rows, Cc, ldx, o2.stride(0), eps, _stream()),
                "ll_rmsnorm")
+    _t1("rmsnorm", t0, 4.0 * rows * Cc)
     return out
 
 
@@ -158,11 +178,13 @@ def qk_norm_rope_kv_store(qkv, wq, wk, rope_f, rope_hw, q_out, cache_k, cache_v,
     assert rope_f.shape == (1024, nf, 2), rope_f.shape
     assert rope_hw.shape == (frame_len, half - nf, 2), rope_hw.shape
     lib = _lib.load()
+    t0 = _t0("qk_norm_rope_kv_store")
     _lib.check(lib.ll_qk_norm_rope_kv_store(qkv.data_ptr(), wq.data_ptr(), wk.data_ptr(), rope_f.data_ptr(),
                                             rope_hw.data_ptr(), q_out.data_ptr(), cache_k.data_ptr(),
                                             cache_v.data_ptr(), B, L, Cc, head_dim, frame_len, start_frame, S,
                                             write_start, roped_offset, write_len, eps, _stream()),
                "ll_qk_norm_rope_kv_store")
+    _t1("qk_norm_rope_kv_store", t0, 2.0 * (qkv.numel() + B * L * Cc + 2 * B * write_len * Cc))   # q,k,v in; q out; k,v -> cache
     return q_out
 
 
@@ -172,11 +194,13 @@ def kv_roll(cache_k, cache_v, dst: int, src: int, n: int):
     Cc = cache_k.numel() // (B * S)
     assert cache_v.shape == cache_k.shape
     lib = _lib.load()
+    t0 = _t0("kv_roll")
     _lib.check(lib.ll_kv_roll(cache_k.data_ptr(), cache_v.data_ptr(), B, S, Cc, dst, src, n, _stream()), "ll_kv_roll")
+    _t1("kv_roll", t0, 2.0 * 2 * 2 * B * n * Cc)     # k and v, read + write, bf16
 
 
 def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
-         rows_per_batch: int = 0, frame_len: int = 0):
+         rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm"):
     """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias).  x may be any [..., K] contiguous tensor."""
     _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias")
     K = x.shape[-1]
@@ -197,12 +221,11 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
         assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
         assert e.numel() == (M // frame_len) * nmod * N, (e.shape, M, frame_len)
     lib = _lib.load()
-    t0 = timer.begin("gemm") if timer is not None else None
+    t0 = _t0(tag)
     _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                 _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
                "ll_gemm_bf16")
-    if timer is not None:
-        timer.end("gemm", t0, 2.0 * M * N * K)
+    _t1(tag, t0, 2.0 * M * N * K)
     return out
 
 
@@ -218,12 +241,14 @@ def quantize_rows(x, q=None, scale=None):
     _chk(q, "q", torch.int8); _chk(scale, "scale", torch.float32)
     assert q.numel() == x.numel() and scale.numel() == rows
     lib = _lib.load()
+    t0 = _t0("quantize_rows")
     _lib.check(lib.ll_quantize_rows(x.data_ptr(), q.data_ptr(), scale.data_ptr(), rows, K, K, _stream()), "ll_quantize_rows")
+    _t1("quantize_rows", t0, 3.0 * x.numel())
     return q, scale
 
 
 def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
-              rows_per_batch: int = 0, frame_len: int = 0):
+              rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm"):
     """out[M,N] = epilogue(sx[m] sw[n] (xq[M,K] @ wq[N,K]^T) + bias): int8 operands, int32 accumulation, bf16 out."""
     _chk(xq, "xq", torch.int8); _chk(wq, "wq", torch.int8); _chk(sx, "sx", torch.float32); _chk(sw, "sw", torch.float32)
     _chk(bias, "bias")
@@ -245,12 +270,11 @@ def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None
         assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
         assert e.numel() == (M // frame_len) * nmod * N
     lib = _lib.load()
-    t0 = timer.begin("gemm") if timer is not None else None
+    t0 = _t0(tag)
     _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
                                 out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
                                 rows_per_batch, frame_len, _stream()), "ll_gemm_w8a8")
-    if timer is not None:
-        timer.end("gemm", t0, 2.0 * M * N * K)
+    _t1(tag, t0, 2.0 * M * N * K)
     return out
 
 

@@ -234,6 +234,8 @@ class WanVAEWrapper(nn.Module):
     def decode_to_pixel(self, latent: torch.Tensor, use_cache: bool = False) -> torch.Tensor:
         if latent.dtype != bf16:
             latent = latent.to(bf16)
+        if use_cache:      # ONE streaming feature cache: a second sample would continue the first one's stream
+            assert latent.shape[0] == 1, "Batch size must be 1 when using cache"          # utils/wan_wrapper.py:99
         out = [self.model.decode(u, keep_cache=use_cache) for u in latent]
         return torch.stack(out, 0)
 

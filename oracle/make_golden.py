@@ -342,6 +342,90 @@ def gen_real_fwd(ns):
     _save("real_fwd.pt", rec)
 
 
+def gen_config1(ns):
+    """BASELINE config 1 (SURVEY section 8c "G5"): LongLive-1.3B shape (30 layers, 832x480 latents), random-init,
+    `denoising_step_list=[1000]`, a 4-latent-frame clip through the REFERENCE's CausalInferencePipeline on CPU in bf16
+    (pipeline/causal_inference.py:56-253).  4 % 3 != 0 (causal_inference.py:77), so num_frame_per_block = 1: four blocks
+    of (1 denoise forward + 1 clean-context forward).  One denoise step => no randn_like draw."""
+    cfg = synth.longlive_1_3b()
+    fs = cfg.frame_seqlen
+    t0 = time.time()
+    sd = synth.synth_state_dict(cfg, seed=0)
+    M = build_ref_model(ns, cfg, sd, fs)
+    del sd
+    wr = build_ref_wrapper(ns, M)
+    print(f"config1 model: {time.time() - t0:.1f}s")
+    table = {"p0": synth.synth_prompt_embeds(cfg, seed=1)}
+    args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000], warp_denoising_step=True, num_frame_per_block=1,
+                           context_noise=0, global_sink=True)
+    P = ns.causal_inference.CausalInferencePipeline(args, "cpu", generator=wr, text_encoder=_fake_text_encoder(table),
+                                                    vae=_FakeVAE())
+    assert (P.num_transformer_blocks, P.frame_seq_length) == (30, fs)
+    noise = synth.synth_noise(cfg, 4, seed=0)
+    t0 = time.time()
+    _, lat = P.inference(noise, ["p0"], return_latents=True)
+    print(f"config1 pipeline (4 frames, 8 forwards): {time.time() - t0:.1f}s")
+    slots = sample_rows(4 * fs, 64)
+    _save("config1_pipe.pt", dict(latents=lat.clone(), slots=slots,
+                                  k_l0=P.kv_cache1[0]["k"][0, slots].clone(), v_l0=P.kv_cache1[0]["v"][0, slots].clone(),
+                                  k_l29=P.kv_cache1[29]["k"][0, slots].clone(), v_l29=P.kv_cache1[29]["v"][0, slots].clone(),
+                                  idx=(int(P.kv_cache1[0]["global_end_index"]), int(P.kv_cache1[0]["local_end_index"])),
+                                  kv_shape=list(P.kv_cache1[0]["k"].shape)))
+
+
+def gen_real_recache(ns):
+    """BASELINE config 4's prompt-switch forward at the real shape, 2 layers: the reference's
+    InteractiveCausalInferencePipeline._recache_after_switch (interactive_causal_inference.py:34-106) re-encodes the last
+    12 frames in ONE forward (L = Lk = 18720) under the new prompt -- with global_sink False (caches zeroed first,
+    sink_recache_after_switch=True) and True (caches kept, sink slots protected).  State before the switch: window full
+    (synthetic cache content, end indices (24 frames, 12 frames)); `output` holds 24 synthetic clean latent frames."""
+    cfg = synth.longlive_1_3b(num_layers=2)
+    fs = cfg.frame_seqlen
+    S = 12 * fs
+    sd = synth.synth_state_dict(cfg, seed=0, layers=[0, 1])
+    M = build_ref_model(ns, cfg, {k: v.float() for k, v in sd.items()}, fs)
+    wr = build_ref_wrapper(ns, M)
+    table = {"p1": synth.synth_prompt_embeds(cfg, seed=2)}
+    output = synth.synth_noise(cfg, 24, seed=7)          # stands in for the clean latents generated so far
+    rec = dict(slots=sample_rows(S, 96), frames=[0, 5, 11])
+    for gs in (False, True):
+        args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                               denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
+                               context_noise=0, global_sink=gs)
+        I = ns.interactive.InteractiveCausalInferencePipeline(args, "cpu", generator=wr,
+                                                              text_encoder=_fake_text_encoder(table), vae=_FakeVAE())
+        I.num_transformer_blocks = 2
+        I.kv_cache1 = ref_kv_cache(1, S, 2, 12, 128)
+        I.crossattn_cache = ref_ca_cache(1, 512, 2, 12, 128)
+        for i, c in enumerate(I.kv_cache1):
+            c["k"], c["v"] = synth_kv_fill(cfg, i, S, S)
+            c["global_end_index"].fill_(24 * fs); c["local_end_index"].fill_(S)
+        I._set_all_modules_max_attention_size(12)
+        x0s = []
+        orig_fwd = wr.forward
+
+        def spy(*a, **k):
+            out = orig_fwd(*a, **k)
+            x0s.append(out[1].clone())
+            return out
+        wr.forward = spy
+        t0 = time.time()
+        try:
+            I._recache_after_switch(output, 24, {"prompt_embeds": table["p1"]})
+        finally:
+            wr.forward = orig_fwd
+        print(f"real recache gs={gs}: {time.time() - t0:.1f}s")
+        assert len(x0s) == 1 and x0s[0].shape[1] == 12
+        tag = f"gs{int(gs)}"
+        rec[tag] = dict(x0_frames=x0s[0][:, rec["frames"]].clone(),
+                        k=[c["k"][0, rec["slots"]].clone() for c in I.kv_cache1],
+                        v=[c["v"][0, rec["slots"]].clone() for c in I.kv_cache1],
+                        idx=(int(I.kv_cache1[0]["global_end_index"]), int(I.kv_cache1[0]["local_end_index"])),
+                        ca_init=[bool(c["is_init"]) for c in I.crossattn_cache])
+    _save("real_recache.pt", rec)
+
+
 def main(argv):
     ns = load_pipelines()
     todo = argv or ["ops", "toy", "pipe", "pipe_calls", "real_block", "real_fwd"]

@@ -55,3 +55,30 @@ def test_reference_cache_dicts_with_tensor_indices():
     ours = {"global_end_index": 0, "local_end_index": 0}
     _kv_commit(ours, 4, 4)
     assert ours["global_end_index"] == 4 and _kv_state(ours) == (4, 4)
+
+
+def test_packed_weights_follow_the_parameters():
+    """The fused QKV copies must never outlive the parameters they were made from: a load through the WRAPPER
+    (inference.py:87/94: `pipeline.generator.load_state_dict`; nn.Module recursion bypasses the child's load_state_dict
+    override) and an in-place update (EMA swap, LoRA re-fold) both invalidate them."""
+    cfg = synth.toy_config()
+    w = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=3, sink_size=1, cfg=cfg, device="cpu",
+                            state_dict=synth.synth_state_dict(cfg, seed=3))
+    m = w.model
+    old = m._pack()[1]["wqkv"].clone()
+    assert m._pack() is m._pack()                                    # cached while nothing changes
+    new_sd = synth.synth_state_dict(cfg, seed=4)
+    res = w.load_state_dict({"model." + k: v for k, v in new_sd.items()})
+    assert not res.missing_keys and not res.unexpected_keys
+    got = m._pack()[1]["wqkv"]
+    want = torch.cat([new_sd[f"blocks.1.self_attn.{n}.weight"] for n in "qkv"], 0)
+    assert torch.equal(got, want) and not torch.equal(got, old)
+    # in-place parameter update (autograd's version counter moves)
+    with torch.no_grad():
+        m.blocks[0].self_attn.k.weight.mul_(2)
+    blk0 = m._pack()[0]["wqkv"]
+    assert torch.equal(blk0[cfg.dim:2 * cfg.dim], m.blocks[0].self_attn.k.weight)
+    # writes through `.data` bypass the version counter: the documented remedy is invalidate_packed()
+    m.blocks[0].self_attn.v.weight.data.mul_(3)
+    m.invalidate_packed()
+    assert torch.equal(m._pack()[0]["wqkv"][2 * cfg.dim:], m.blocks[0].self_attn.v.weight)

@@ -184,10 +184,91 @@ static void bench_attn(const char* name, int Lq, int H, int Sk, int n0, int iter
          4.0 * Lq * (double)n0 * 128 * H / (ms * 1e-3) / 1e12, worst, worst > 1e-2 ? "**FAIL**" : "");
 }
 
+
+// ---- "shipped": exactly the launches of ONE steady-state DiT layer under the default tuning, one timing line each plus a
+// machine-readable "#WORK" record (kernel-name substring, grid, algorithmic FLOPs / bytes, us) that tools/pmc_summary.py
+// joins with the rocprofv3 --pmc counters of the same command.
+static void work_line(const char* tag, const char* match, double flop, double bytes, double us, const char* bound) {
+  printf("#WORK {\"tag\": \"%s\", \"match\": \"%s\", \"flop\": %.6g, \"bytes\": %.6g, \"us\": %.3f, \"bound\": \"%s\"}\n", tag, match,
+         flop, bytes, us, bound);
+}
+
+static void bench_shipped(int iters) {
+  const int L = 4680, C = 1536, F1 = 8960, S = 18720, H = 12, FS = 1560;
+  hipStream_t s = 0;
+  char plan[256];
+  // ---- MFMA kernels
+  struct G { const char* tag; int N, K, epi; } gs[] = {{"gemm_qkv", 3 * C, C, LL_EPI_BIAS}, {"gemm_o", C, C, LL_EPI_BIAS_GATE_RES},
+      {"gemm_cq", C, C, LL_EPI_BIAS}, {"gemm_co", C, C, LL_EPI_BIAS_RES}, {"gemm_f1", F1, C, LL_EPI_BIAS_GELU},
+      {"gemm_f2", C, F1, LL_EPI_BIAS_GATE_RES}};
+  for (auto& g : gs) {
+    Buf x((size_t)L * g.K, 1.0f), w((size_t)g.N * g.K, 1.0f / sqrtf((float)g.K)), bias(g.N, 0.1f), out((size_t)L * g.N, 0.f);
+    Buf res((size_t)L * g.N, 1.0f), e((size_t)3 * 6 * g.N, 0.5f), mod((size_t)6 * g.N, 0.1f);
+    double ms = time_ms(s, iters, [&]() {
+      LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, mod.d, 6, 2, L, FS, s));
+    });
+    LL(ll_gemm_plan(L, g.N, g.K, 0, plan, sizeof plan));
+    double fl = 2.0 * L * g.N * g.K, by = 2.0 * ((double)L * g.K + (double)g.N * g.K + (double)L * g.N * (g.epi >= 2 ? 2 : 1));
+    printf("%-10s %-60s %8.1f us %7.1f TFLOP/s\n", g.tag, plan, ms * 1e3, fl / (ms * 1e-3) / 1e12);
+    char match[64];
+    snprintf(match, sizeof match, "%.14s<%d", plan, g.epi);      // gemm_kernel_vN<EPI
+    work_line(g.tag, match, fl, by, ms * 1e3, "mfma");
+  }
+  {
+    Buf q((size_t)L * C, 1.0f), k((size_t)S * C, 1.0f), v((size_t)S * C, 0.7f), o((size_t)L * C, 0.f);
+    float scale = 1.0f / sqrtf(128.f);
+    double ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, L, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, s)); });
+    LL(ll_flash_attn_plan(L, H, 1, S, 0, 1, plan, sizeof plan));
+    double fl = 4.0 * L * (double)S * 128 * H;
+    printf("%-10s %-60.60s %8.1f us %7.1f TFLOP/s\n", "attn_self", plan, ms * 1e3, fl / (ms * 1e-3) / 1e12);
+    work_line("flash_attn_self", "flash_attn_pipe_kernel<8, 1>", fl, 2.0 * (2.0 * L * C + 2.0 * S * C), ms * 1e3, "mfma");
+    Buf kc((size_t)512 * C, 1.0f), vc((size_t)512 * C, 0.7f);
+    ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, kc.d, vc.d, o.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, s)); });
+    fl = 4.0 * L * 512.0 * 128 * H;
+    printf("%-10s %-60.60s %8.1f us %7.1f TFLOP/s\n", "attn_cross", "flash_attn_pipe_kernel<8, 0> (512 text keys)", ms * 1e3, fl / (ms * 1e-3) / 1e12);
+    work_line("flash_attn_cross", "flash_attn_pipe_kernel<8, 0>", fl, 2.0 * (2.0 * L * C + 2.0 * 512 * C), ms * 1e3, "mfma");
+  }
+  // ---- row kernels (HBM-bound)
+  {
+    Buf x((size_t)L * C, 1.7f), out((size_t)L * C, 0.f), e((size_t)3 * 6 * C, 0.5f), mod((size_t)6 * C, 0.1f), w(C, 0.1f), b(C, 0.1f);
+    double ms = time_ms(s, iters, [&]() { LL(ll_ln_modulate(x.d, out.d, e.d, mod.d, 6, 0, 1, 1, L, C, 3, 1e-6f, s)); });
+    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "ln_mod", "ln_modulate_kernel", ms * 1e3, 4.0 * L * C / (ms * 1e-3) / 1e9);
+    work_line("ln_modulate", "ln_modulate_kernel", 0, 4.0 * L * C, ms * 1e3, "hbm");
+    ms = time_ms(s, iters, [&]() { LL(ll_layernorm_affine(x.d, w.d, b.d, out.d, L, C, 1e-6f, s)); });
+    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "ln_affine", "layernorm_affine_kernel", ms * 1e3, 4.0 * L * C / (ms * 1e-3) / 1e9);
+    work_line("layernorm_affine", "layernorm_affine_kernel", 0, 4.0 * L * C, ms * 1e3, "hbm");
+    ms = time_ms(s, iters, [&]() { LL(ll_rmsnorm(x.d, w.d, out.d, L, C, C, C, 1e-6f, s)); });
+    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "rmsnorm", "rmsnorm_kernel", ms * 1e3, 4.0 * L * C / (ms * 1e-3) / 1e9);
+    work_line("rmsnorm", "rmsnorm_kernel", 0, 4.0 * L * C, ms * 1e3, "hbm");
+  }
+  {
+    Buf qkv((size_t)L * 3 * C, 1.3f), wq(C, 0.1f), wk(C, 0.1f), qo((size_t)L * C, 0.f), ck((size_t)S * C, 1.0f), cv((size_t)S * C, 1.0f);
+    float *rf, *rhw;
+    std::vector<float> hrf((size_t)1024 * 22 * 2), hrhw((size_t)FS * 42 * 2);
+    for (auto& t : hrf) t = 0.5f;
+    for (auto& t : hrhw) t = 0.5f;
+    CK(hipMalloc(&rf, hrf.size() * 4)); CK(hipMalloc(&rhw, hrhw.size() * 4));
+    CK(hipMemcpy(rf, hrf.data(), hrf.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(rhw, hrhw.data(), hrhw.size() * 4, hipMemcpyHostToDevice));
+    double ms = time_ms(s, iters, [&]() {
+      LL(ll_qk_norm_rope_kv_store(qkv.d, wq.d, wk.d, rf, rhw, qo.d, ck.d, cv.d, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
+    });
+    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "qk_rope_kv", "qk_norm_rope_kv_kernel", ms * 1e3, 12.0 * L * C / (ms * 1e-3) / 1e9);
+    work_line("qk_norm_rope_kv_store", "qk_norm_rope_kv_kernel", 0, 12.0 * L * C, ms * 1e3, "hbm");
+    ms = time_ms(s, iters, [&]() { LL(ll_kv_roll(ck.d, cv.d, 1, S, C, 3 * FS, 6 * FS, 6 * FS, s)); });
+    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "kv_roll", "copy_rows_kernel (2 launches)", ms * 1e3, 8.0 * 6 * FS * C / (ms * 1e-3) / 1e9);
+    work_line("kv_roll", "copy_rows_kernel", 0, 8.0 * 6 * FS * C, ms * 1e3, "hbm");
+    hipFree(rf); hipFree(rhw);
+  }
+}
+
 int main(int argc, char** argv) {
   const char* what = argc > 1 ? argv[1] : "all";
   int iters = argc > 2 ? atoi(argv[2]) : 20;
   bool all = !strcmp(what, "all");
+  if (!strcmp(what, "shipped")) {
+    bench_shipped(iters);
+    return 0;
+  }
   if (all || !strcmp(what, "gemm")) {
    for (int variant = 2; variant <= 6; ++variant) {
     LL(ll_set_tuning("gemm_variant", variant));
