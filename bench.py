@@ -250,9 +250,9 @@ def kernel_table(summary, quant):
         if tag in gemm_shapes:
             name = _plan_text(lib.ll_gemm_plan, *gemm_shapes[tag], i8)
         elif tag == "flash_attn_self":
-            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1)
+            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)
         elif tag == "flash_attn_cross":
-            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1)
+            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1, 1)
         else:
             name = {"ln_modulate": "ln_modulate_kernel", "layernorm_affine": "layernorm_affine_kernel", "rmsnorm": "rmsnorm_kernel",
                     "qk_norm_rope_kv_store": "qk_norm_rope_kv_kernel", "kv_roll": "copy_rows_kernel",
@@ -431,7 +431,7 @@ def run_replica(args, rank, world, local_rank, sync):
                     break
                 except Exception:
                     traffic = None
-        res["roofline"] = {"bound": "mfma", "kernel": _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1)
+        res["roofline"] = {"bound": "mfma", "kernel": _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1, 1)
                            + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,
                            "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_source": src, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],

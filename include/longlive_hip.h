@@ -45,12 +45,15 @@ const char* ll_last_error(void);
 /* Development knob for A/B timing of kernel variants (tools/kbench, tools/kenergy, LL_TUNING=key=value,... for bench.py);
  * the defaults are the shipped configuration.  Keys: "gemm_variant" 0 = auto (cost model), 2 = 256x128, 3 = 256x256,
  * 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;  "attn_variant" 0 = simple, 1 = software-pipelined, 2 = + ping-pong wave
- * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on.  Unknown key: LL_ERR_INVALID_ARG. */
+ * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on;  "attn_sk_wgs" -1 = stream-K attention off
+ * (default: measured slower at the power limit), 0 = on when it shortens the walk, N = force N workgroups;  "gemm_group_m" = m-tiles per group of the GEMM tile walk
+ * (default 4; <= 1: N fastest).  Unknown key: LL_ERR_INVALID_ARG. */
 int ll_set_tuning(const char* key, int value);
 /* Host-only introspection: the kernel instance + tile + grid that ll_gemm_bf16 / ll_gemm_w8a8 / ll_flash_attn would launch
  * for a shape under the current tuning, as text in out[cap] (bench.py's per-kernel table names kernels from here). */
 int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap);
-int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, char* out, int cap);
+int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, int have_workspace, char* out,
+                       int cap);
 
 /* ---- norms / modulation ------------------------------------------------------------------------------------- */
 
@@ -124,10 +127,16 @@ int ll_linear_small(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_
  * ([seg0_start, +seg0_len) then [seg1_start, +seg1_len)): frame sink + sliding window of the KV cache, or the 512
  * text tokens for cross-attention.  Replaces attention()/flash_attention() (wan/modules/attention.py:43-197) and the
  * sink/window gather + cat (wan/modules/causal_model.py:331-360).
- *   q,out [B, Lq, H*128] with row strides ldq/ldo; k,v [B, Sk, H*128] with row stride ldk, batch stride Sk*ldk. */
+ *   q,out [B, Lq, H*128] with row strides ldq/ldo; k,v [B, Sk, H*128] with row stride ldk, batch stride Sk*ldk.
+ *   workspace (optional, may be NULL): >= ll_flash_attn_workspace_bytes() bytes of 16-byte-aligned device scratch owned by
+ *   the caller (the ABI never allocates).  Only read when the stream-K form is enabled (ll_set_tuning "attn_sk_wgs" >= 0): a
+ *   long contiguous key range is then cut into equal runs of 64-key tiles over ALL CUs (a launch of 228 (head, q-tile) pairs
+ *   otherwise leaves 28 of the 256 CUs idle) and split pairs are merged by a second small launch on the same stream.
+ *   Contents need no initialisation. */
 int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H, int ldq,
                   int ldo, int ldk, long long k_batch_stride, int seg0_start, int seg0_len, int seg1_start,
-                  int seg1_len, float scale, ll_stream stream);
+                  int seg1_len, float scale, void* workspace, long long workspace_bytes, ll_stream stream);
+long long ll_flash_attn_workspace_bytes(void);
 
 /* ---- embeddings / head / scheduler ------------------------------------------------------------------------------ */
 

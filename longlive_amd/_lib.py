@@ -19,7 +19,8 @@ SIGNATURES = {
     "ll_last_error": [],
     "ll_set_tuning": [C.c_char_p, _i],
     "ll_gemm_plan": [_i, _i, _i, _i, C.c_char_p, _i],
-    "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, C.c_char_p, _i],
+    "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
+    "ll_flash_attn_workspace_bytes": [],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ll_ln_modulate_q8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
@@ -31,7 +32,7 @@ SIGNATURES = {
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ll_quantize_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ll_linear_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p],
+    "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p, _ll, _p],
     "ll_patchify": [_p, _p, _i, _i, _i, _i, _i, _p],
     "ll_sinusoid": [_p, _p, _i, _i, _p],
     "ll_unpatchify_x0": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -47,7 +48,7 @@ SIGNATURES = {
     "ll_gather_rows": [_p, _p, _p, _i, _i, _ll, _p],
     "ll_t5_attention": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
-_RESTYPES = {"ll_last_error": C.c_char_p}
+_RESTYPES = {"ll_last_error": C.c_char_p, "ll_flash_attn_workspace_bytes": C.c_longlong}
 
 _lib = None
 

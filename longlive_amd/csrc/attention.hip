@@ -597,8 +597,331 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
   }
 }
 
+
+// =================================================================================================================
+// Stream-K form of the ping-pong kernel: the (batch, head, 256-row q-tile) x key-tile work of a launch is cut into W equal
+// CONTIGUOUS ranges of 64-key tile units, one per workgroup, W = number of CUs.
+//
+// Why: a launch is ONE round of workgroups (one per CU, 112 KiB of LDS each), so its duration is the tile count of the
+// busiest CU.  The steady-state self-attention has 12 heads x 19 q-tiles = 228 (head, q-tile) pairs of 293 key tiles: 228
+// CUs walk 293 tiles, 28 CUs idle.  Cut as 256 x 261 tiles every CU works and the walk is 11 % shorter (the recache launch,
+// 888 pairs: 4 rounds of 293 -> 1017).  A workgroup's range covers the tail of one pair, possibly whole pairs, and the head
+// of another; a part that is not a whole pair leaves (unnormalised O^T in fp32, running max, running sum) in a workspace
+// slot and flash_attn_sk_combine_kernel merges the 2-3 parts of every split pair (log-sum-exp merge) into the bf16 output.
+//
+// Order inside a workgroup: LAST pair first.  All workgroups then start at key tile 0 together and, after the switch to
+// their earlier pair, sit at one common offset again: the workgroups of a head form two fronts that stream the same K/V
+// tiles at the same time, so the per-XCD L2 still serves most of them (walking the range in ascending order instead puts
+// every workgroup at a different key offset: ~2 GB of L2 misses per launch).
+//
+// Everything inside a part -- LDS-DMA staging, rings, SM / MM phases, the barrier-shifted wave groups, register layout -- is
+// flash_attn_pipe_kernel<NW, 1>'s, tile by tile; outputs of unsplit pairs are bit-identical to it.
+#define SK_KSTAGES 3
+#define SK_VSTAGES 4
+#define SK_SLOT_FLOATS(NW) ((NW) * 32 * 128 + 2 * (NW) * 32)      // O^T image + m + l of one part
+
+// first tile unit of workgroup w; the launcher guarantees U * W < 2^31 (32-bit divisions: the 64-bit ones are software loops)
+__device__ __forceinline__ int sk_start(int w, int U, int W) { return (int)(((unsigned)w * (unsigned)U) / (unsigned)W); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void flash_attn_sk_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
+                                                                    const bf16* __restrict__ Vc, bf16* __restrict__ O,
+                                                                    float* __restrict__ ws, int Lq, int ldq, int ldo, int ldk,
+                                                                    long long k_batch_stride, int kstart, int nkeys, float c,
+                                                                    int nqt, int H, int npairs, int xcd_placement) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 K stages][4 V stages] x 16 KiB
+  char* const ksm = smem;
+  char* const vsm = smem + SK_KSTAGES * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int W = gridDim.x;
+  const int bid = blockIdx.x;
+  // ids that share an XCD (id % 8) take consecutive ranges: one head's K/V stream meets ~2 of the 8 L2s
+  const int lid = (xcd_placement > 0 && (W & 7) == 0) ? (bid & 7) * (W >> 3) + (bid >> 3) : bid;
+  const int nt = (nkeys + KT - 1) / KT;
+  const int last_valid = nkeys - (nt - 1) * KT;
+  const int U = npairs * nt;
+  const int u0 = sk_start(lid, U, W), u1 = sk_start(lid + 1, U, W);
+  if (u0 >= u1) return;                                   // more workgroups than tile units (uniform: no barrier is pending)
+  const int p_first = u0 / nt, p_last = (u1 - 1) / nt;
+
+  constexpr int NDMA = 16 / NW;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int dma_key[NDMA], dma_kch[NDMA], dma_vch[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    int key = 4 * (wave * NDMA + i) + (lane >> 4), pos = lane & 15;
+    dma_key[i] = key;
+    dma_kch[i] = (pos ^ (key & 15)) * 16;
+    dma_vch[i] = (pos ^ ((key & 3) << 2)) * 16;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int late = __builtin_amdgcn_readfirstlane(wave >= NW / 2);
+  int k_off[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_off[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) << 4);
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+  int v_off[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    int dbyte = (32 * db + 16 * tg1 + 4 * tp) * 2;
+    v_off[db] = (4 * h + tq) * 256 + (((dbyte >> 4) ^ (tq << 2)) << 4) + (dbyte & 15);
+  }
+  typedef __attribute__((ext_vector_type(8))) short sk_s16x8;
+
+  for (int p = p_last; p >= p_first; --p) {
+    const int pb = p * nt;
+    const int tb = (u0 > pb ? u0 : pb) - pb;                              // this part = key tiles [tb, te) of pair p
+    const int te = (u1 < pb + nt ? u1 : pb + nt) - pb;
+    const int qtile = p % nqt, head = (p / nqt) % H, b = p / (nqt * H);
+    const int q0 = qtile * (NW * 32) + wave * 32;
+    const bf16* kh = Kc + (size_t)b * k_batch_stride + (size_t)kstart * ldk + head * 128;
+    const bf16* vh = Vc + (size_t)b * k_batch_stride + (size_t)kstart * ldk + head * 128;
+
+    bf16x8 qf[8];
+    {
+      int qr = q0 + r;
+      qr = qr < Lq ? qr : Lq - 1;
+      const bf16* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 128 + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+#define SK_DMA(T, KS, VS)                                                                        \
+  {                                                                                              \
+    int t_ = (T) < te ? (T) : te - 1;                                                            \
+    int valid_ = (t_ == nt - 1) ? last_valid : KT;                                               \
+    const char* kt_ = reinterpret_cast<const char*>(kh) + (size_t)t_ * KT * ldk * 2;            \
+    const char* vt_ = reinterpret_cast<const char*>(vh) + (size_t)t_ * KT * ldk * 2;            \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDMA; ++i_) {                                        \
+      int key_ = dma_key[i_] < valid_ ? dma_key[i_] : valid_ - 1;                                \
+      unsigned row_ = (unsigned)key_ * (unsigned)ldk * 2u;                                       \
+      int j_ = wave_u * NDMA + i_;                                                               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kt_ + row_ + dma_kch[i_]), (lptr_t)(ksm + (KS) * TILE_B + j_ * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_ + row_ + dma_vch[i_]), (lptr_t)(vsm + (VS) * TILE_B + j_ * 1024), 16, 0, 0); \
+    }                                                                                            \
+  }
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- prologue: tiles tb, tb + 1 into LDS, S(tb) ----------------------------------------------------------------------
+    SK_DMA(tb, 0, 0);
+    SK_DMA(tb + 1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 s_cur[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_cur[kb][i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(ksm + k_off[ks] + kb * 8192);
+        s_cur[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_cur[kb], 0, 0, 0);
+      }
+    __syncthreads();   // K stage 0 is overwritten by the first iteration's staging
+
+    uint4 pw[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) pw[kb][s2] = make_uint4(0, 0, 0, 0);
+#define SK_SM(T)                                                                                 \
+  {                                                                                              \
+    if ((T) == nt - 1 && last_valid < KT) {                                                      \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                           \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                           \
+        int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;                                      \
+        if (key >= last_valid) s_cur[kb][i] = -INFINITY;                                         \
+      }                                                                                          \
+    }                                                                                            \
+    float mx = s_cur[0][0];                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_cur[kb][i]);                 \
+    mx = xhalf_max(mx);                                                                          \
+    float m_new = fmaxf(m_run, mx);                                                              \
+    float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                   \
+    float mc = m_new * c;                                                                        \
+    float rs = 0.f;                                                                              \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                           \
+      float p_[8];                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+        p_[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));           \
+        rs += p_[j];                                                                             \
+      }                                                                                          \
+      pw[kb][s2] = make_uint4(pack_bf16x2(p_[0], p_[1]), pack_bf16x2(p_[2], p_[3]), pack_bf16x2(p_[4], p_[5]), \
+                              pack_bf16x2(p_[6], p_[7]));                                        \
+    }                                                                                            \
+    rs = xhalf_sum(rs);                                                                          \
+    l_run = l_run * alpha + rs;                                                                  \
+    if (__any(m_new != m_run)) {                                                                 \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d)                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) o[d][i] *= alpha;                           \
+    }                                                                                            \
+    m_run = m_new;                                                                               \
+  }
+#define SK_MM(VS, KS)                                                                            \
+  {                                                                                              \
+    const char* vc = vsm + (VS) * TILE_B;                                                        \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                           \
+      bf16x8 pfrag = __builtin_bit_cast(bf16x8, pw[kb][s2]);                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                         \
+        const char* a0 = vc + v_off[db] + (32 * kb + 16 * s2) * 256;                             \
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));                 \
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 8 * 256));       \
+        sk_s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                   \
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pfrag, o[db], 0, 0, 0); \
+      }                                                                                          \
+    }                                                                                            \
+    const char* kn = ksm + (KS) * TILE_B;                                                        \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) s_cur[kb][i] = 0.f;                           \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks)                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                           \
+      bf16x8 kf = *reinterpret_cast<const bf16x8*>(kn + k_off[ks] + kb * 8192);                  \
+      s_cur[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_cur[kb], 0, 0, 0);       \
+    }                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);                                          \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); \
+  }
+    // always true for waves that own query rows, but opaque to the compiler: each phase becomes its own scheduling region
+    const bool own_block = xcd_placement >= 0 && qtile * (NW * 32) + wave_u * 32 < Lq;
+    if (late) __syncthreads();
+    int kq = 1, kd = 2, vq = 0, vd = 2;      // slots: K(t+1), K(t+2), V(t), V(t+2)
+    for (int t = tb; t < te; ++t) {
+      SK_DMA(t + 2, kd, vd);
+      if (own_block) SK_SM(t);
+      __syncthreads();
+      __builtin_amdgcn_s_setprio(1);
+      if (own_block) SK_MM(vq, kq);
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      kq = kd;
+      kd = kd == SK_KSTAGES - 1 ? 0 : kd + 1;
+      vq = vq == SK_VSTAGES - 1 ? 0 : vq + 1;
+      vd = vd == SK_VSTAGES - 1 ? 0 : vd + 1;
+    }
+    if (!late) __syncthreads();
+#undef SK_DMA
+#undef SK_SM
+#undef SK_MM
+
+    const int qr = q0 + r;
+    if (tb == 0 && te == nt) {                           // a whole pair: final output, as the unsplit kernel writes it
+      if (qr < Lq) {
+        float inv = 1.0f / l_run;
+        bf16* op = O + ((size_t)b * Lq + qr) * ldo + head * 128 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            uint2 w;
+            w.x = pack_bf16x2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
+            w.y = pack_bf16x2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 32 * db + 8 * g4) = w;
+          }
+      }
+    } else {                                             // a part: the lane image of O^T (fully coalesced 1 KiB stores), m, l
+      const int slot = 2 * lid + (tb > 0 ? 0 : 1);
+      float* sp = ws + (size_t)slot * SK_SLOT_FLOATS(NW);
+      float4* op = reinterpret_cast<float4*>(sp) + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          op[(db * 4 + g4) * 64] = make_float4(o[db][4 * g4], o[db][4 * g4 + 1], o[db][4 * g4 + 2], o[db][4 * g4 + 3]);
+      if (h == 0) {
+        sp[NW * 32 * 128 + wave * 32 + r] = m_run;
+        sp[NW * 32 * 128 + NW * 32 + wave * 32 + r] = l_run;
+      }
+    }
+  }
+}
+
+// Merges the parts of every split (batch, head, q-tile) pair: O = sum_i O_i 2^(c (m_i - M)) / sum_i l_i 2^(c (m_i - M)),
+// M = max_i m_i.  One workgroup per pair, the attention kernel's thread geometry (each lane re-reads exactly the float4s a
+// lane of that geometry wrote).  The enumeration of a pair's parts mirrors the kernel's range arithmetic (sk_start).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void flash_attn_sk_combine_kernel(const float* __restrict__ ws, bf16* __restrict__ O,
+                                                                        int Lq, int ldo, int nkeys, float c, int nqt, int H,
+                                                                        int npairs, int W) {
+  const int p = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = (nkeys + KT - 1) / KT;
+  const int U = npairs * nt;
+  const int pb = p * nt, pe = pb + nt;
+  int w = (int)(((unsigned)pb * (unsigned)W) / (unsigned)U);   // owner of unit pb: largest w with sk_start(w) <= pb
+  while (w + 1 < W && sk_start(w + 1, U, W) <= pb) ++w;
+  while (w > 0 && sk_start(w, U, W) > pb) --w;
+  if (sk_start(w, U, W) <= pb && sk_start(w + 1, U, W) >= pe) return;      // unsplit pair: the kernel wrote the output
+  const int qtile = p % nqt, head = (p / nqt) % H, b = p / (nqt * H);
+  const int qr = qtile * (NW * 32) + wave * 32 + r;
+  if (qtile * (NW * 32) + wave * 32 >= Lq) return;       // padding wave of the last q-tile (nothing was computed for it)
+  const int w0 = w;
+  float M = -INFINITY;
+  for (w = w0; w < W && sk_start(w, U, W) < pe; ++w) {
+    int slot = 2 * w + (sk_start(w, U, W) > pb ? 0 : 1);
+    M = fmaxf(M, ws[(size_t)slot * SK_SLOT_FLOATS(NW) + NW * 32 * 128 + wave * 32 + r]);
+  }
+  float acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+  float L = 0.f;
+  for (w = w0; w < W && sk_start(w, U, W) < pe; ++w) {
+    int slot = 2 * w + (sk_start(w, U, W) > pb ? 0 : 1);
+    const float* sp = ws + (size_t)slot * SK_SLOT_FLOATS(NW);
+    float f = __builtin_amdgcn_exp2f((sp[NW * 32 * 128 + wave * 32 + r] - M) * c);
+    L += sp[NW * 32 * 128 + NW * 32 + wave * 32 + r] * f;
+    const float4* op = reinterpret_cast<const float4*>(sp) + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float4 v = op[i * 64];
+      acc[4 * i] += v.x * f; acc[4 * i + 1] += v.y * f; acc[4 * i + 2] += v.z * f; acc[4 * i + 3] += v.w * f;
+    }
+  }
+  if (qr < Lq) {
+    float inv = 1.0f / L;
+    bf16* op = O + ((size_t)b * Lq + qr) * ldo + head * 128 + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        int i = (db * 4 + g4) * 4;
+        uint2 wv;
+        wv.x = pack_bf16x2(acc[i] * inv, acc[i + 1] * inv);
+        wv.y = pack_bf16x2(acc[i + 2] * inv, acc[i + 3] * inv);
+        *reinterpret_cast<uint2*>(op + 32 * db + 8 * g4) = wv;
+      }
+  }
+}
+
 static int g_attn_variant = 2;   // 0: simple kernel, 1: software-pipelined, 2: + ping-pong wave groups for long key ranges
 static int g_attn_xcd = 1;
+// stream-K: -1 = off (DEFAULT), 0 = auto (one workgroup per CU when it shortens the walk), N > 0 = force N workgroups.
+// Off by default because it LOSES on this chip although it removes the idle CUs: interleaved A/B of bench.py on one device,
+// steady-state self-attention 532 us (228 workgroups x 293 tiles) vs 589 us (256 x 261 tiles + combine), 73.4 vs 69.8 frames/s
+// (profiles/r02_ab_streamk_groupm.txt).  The launch already runs at the board's power limit: 12 % more active CUs lower the
+// clock by about as much, and the parts' fp32 round trip (65 MB) and the second key-tile front per head add traffic on top.
+static int g_attn_sk_wgs = -1;
+void ll_set_attn_sk_internal(int v) { g_attn_sk_wgs = v; }
 void ll_set_attn_xcd_internal(int v) { g_attn_xcd = v; }   // 0: simple kernel, 1: software-pipelined kernel (single key range)
 void ll_set_attn_variant_internal(int v) { g_attn_variant = v; }
 
@@ -627,28 +950,89 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
   return ll_check_launch("ll_flash_attn(pipe)");
 }
 
+static int attn_num_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+// Stream-K decision for one contiguous key range: the number of workgroups (0 = use the one-workgroup-per-pair kernel).
+// One round of workgroups walks ceil(pairs / CUs) * nt tiles today; cut evenly it is ceil(pairs * nt / W) plus the parts'
+// epilogues and the combine launch (priced at 12 tiles).
+static int attn_sk_workgroups(int B, int Lq, int H, int nkeys, long long workspace_bytes, int ncu) {
+  if (g_attn_variant < 2 || g_attn_sk_wgs < 0 || nkeys < 16 * KT) return 0;
+  const long long nqt = (Lq + 255) / 256, npairs = (long long)B * H * nqt, nt = (nkeys + KT - 1) / KT;
+  int W = g_attn_sk_wgs > 0 ? g_attn_sk_wgs : ncu;
+  if (npairs * nt * (W + 1) >= 0x7fffffffLL) return 0;      // the kernels' range arithmetic is 32-bit
+  if ((long long)W * 2 * SK_SLOT_FLOATS(8) * 4 > workspace_bytes) return 0;
+  if (g_attn_sk_wgs > 0) return W;
+  long long now = ((npairs + ncu - 1) / ncu) * nt, cut = (npairs * nt + W - 1) / W + 12;
+  return (npairs * nt >= 64LL * W && cut * 100 < now * 97) ? W : 0;
+}
+
+extern "C" long long ll_flash_attn_workspace_bytes(void) {
+  int w = g_attn_sk_wgs > 0 ? g_attn_sk_wgs : attn_num_cus();
+  return (long long)w * 2 * SK_SLOT_FLOATS(8) * 4;
+}
+
 // Which kernel instance ll_flash_attn launches for these key ranges under the current tuning (host only).
-extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, char* out, int cap) {
+extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, int have_workspace,
+                                  char* out, int cap) {
   LL_REQUIRE(out != nullptr && cap > 0, "ll_flash_attn_plan: needs an output buffer");
   int n0 = seg0_len, n1 = seg1_len;
   if (n1 > 0 && seg_adjacent) { n0 += n1; n1 = 0; }
   if (g_attn_variant >= 1 && n1 == 0) {
     int nqt = (Lq + 255) / 256;
     bool pp = g_attn_variant >= 2 && n0 >= 16 * KT;
-    snprintf(out, (size_t)cap, "flash_attn_pipe_kernel<8, %d> (%s), %d workgroups of 256 query rows%s", pp ? 1 : 0,
-             pp ? "ping-pong wave groups" : "one-barrier loop", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
+    int W = have_workspace ? attn_sk_workgroups(B, Lq, H, n0, 1LL << 40, attn_num_cus()) : 0;
+    if (W > 0)
+      snprintf(out, (size_t)cap, "flash_attn_sk_kernel<8> (ping-pong wave groups, stream-K), %d workgroups x %lld key tiles + "
+               "flash_attn_sk_combine_kernel<8>", W, ((long long)nqt * H * B * ((n0 + KT - 1) / KT) + W - 1) / W);
+    else
+      snprintf(out, (size_t)cap, "flash_attn_pipe_kernel<8, %d> (%s), %d workgroups of 256 query rows%s", pp ? 1 : 0,
+               pp ? "ping-pong wave groups" : "one-barrier loop", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
   } else {
     snprintf(out, (size_t)cap, "flash_attn_kernel<4>, %d workgroups of 128 query rows", ((Lq + 127) / 128) * H * B);
   }
   return LL_OK;
 }
 
+static int flash_attn_sk_launch(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H,
+                                int ldq, int ldo, int ldk, long long k_batch_stride, int kstart, int nkeys, float c,
+                                float* ws, int W, ll_stream stream) {
+  constexpr int NW = 8;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)flash_attn_sk_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((SK_KSTAGES + SK_VSTAGES) * TILE_B));
+    attr = true;
+  }
+  const int nqt = (Lq + NW * 32 - 1) / (NW * 32), npairs = B * H * nqt;
+  hipLaunchKernelGGL((flash_attn_sk_kernel<NW>), dim3(W), dim3(NW * 64), (SK_KSTAGES + SK_VSTAGES) * TILE_B, (hipStream_t)stream,
+                     (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, ws, Lq, ldq, ldo, ldk, k_batch_stride, kstart,
+                     nkeys, c, nqt, H, npairs, g_attn_xcd);
+  int rc = ll_check_launch("ll_flash_attn(stream-K)");
+  if (rc) return rc;
+  hipLaunchKernelGGL((flash_attn_sk_combine_kernel<NW>), dim3(npairs), dim3(NW * 64), 0, (hipStream_t)stream, (const float*)ws,
+                     (bf16*)out, Lq, ldo, nkeys, c, nqt, H, npairs, W);
+  return ll_check_launch("ll_flash_attn(stream-K combine)");
+}
+
 extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H,
                              int ldq, int ldo, int ldk, long long k_batch_stride, int seg0_start, int seg0_len,
-                             int seg1_start, int seg1_len, float scale, ll_stream stream) {
+                             int seg1_start, int seg1_len, float scale, void* workspace, long long workspace_bytes,
+                             ll_stream stream) {
   LL_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && ldk % 8 == 0, "ll_flash_attn: row strides must be multiples of 8 elements");
   LL_REQUIRE(ldq >= H * 128 && ldo >= H * 128 && ldk >= H * 128, "ll_flash_attn: row stride smaller than H*128");
   LL_REQUIRE(seg0_len > 0 && seg1_len >= 0 && seg0_start >= 0 && seg1_start >= 0, "ll_flash_attn: needs a non-empty first key range");
+  LL_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "ll_flash_attn: workspace_bytes without a workspace");
+  LL_REQUIRE(((uintptr_t)workspace & 15) == 0, "ll_flash_attn: workspace must be 16-byte aligned");
   if (B == 0 || Lq == 0 || H == 0) return LL_OK;
   Segs sg;
   sg.s0 = seg0_start; sg.n0 = seg0_len; sg.s1 = seg1_start; sg.n1 = seg1_len;
@@ -656,12 +1040,16 @@ extern "C" int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* 
   sg.nt0 = (sg.n0 + KT - 1) / KT;
   sg.nt = sg.nt0 + (sg.n1 + KT - 1) / KT;
   float c = scale * 1.4426950408889634f;
-  if (g_attn_variant >= 1 && sg.n1 == 0)
+  if (g_attn_variant >= 1 && sg.n1 == 0) {
+    int W = workspace ? attn_sk_workgroups(B, Lq, H, sg.n0, workspace_bytes, attn_num_cus()) : 0;
+    if (W > 0)
+      return flash_attn_sk_launch(q, k, v, out, B, Lq, H, ldq, ldo, ldk, k_batch_stride, sg.s0, sg.n0, c, (float*)workspace, W,
+                                  stream);
     return flash_attn_pipe_launch(q, k, v, out, B, Lq, H, ldq, ldo, ldk, k_batch_stride, sg.s0, sg.n0, c, stream);
+  }
   constexpr int NW = 4;
   dim3 grid((Lq + NW * 32 - 1) / (NW * 32), H, B), block(NW * 64);
   hipLaunchKernelGGL(flash_attn_kernel<NW>, grid, block, 4 * TILE_B, (hipStream_t)stream, (const bf16*)q, (const bf16*)k,
                      (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk, k_batch_stride, sg, c);
   return ll_check_launch("ll_flash_attn");
 }
-

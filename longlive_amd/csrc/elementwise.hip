@@ -469,7 +469,9 @@ extern "C" int ll_qk_norm_rope_kv_store(const ll_bf16* qkv, const ll_bf16* wq, c
   LL_REQUIRE(head_dim > 0 && head_dim % 8 == 0 && C % head_dim == 0, "ll_qk_norm_rope_kv_store: bad head_dim %d", head_dim);
   LL_REQUIRE(frame_len > 0 && L % frame_len == 0, "ll_qk_norm_rope_kv_store: L=%d not a whole number of frames (%d)", L, frame_len);
   LL_REQUIRE(start_frame >= 0 && start_frame + L / frame_len <= 1024, "ll_qk_norm_rope_kv_store: frame index beyond the 1024-entry RoPE table");
-  LL_REQUIRE(write_len >= 0 && roped_offset >= 0 && roped_offset + write_len <= L, "ll_qk_norm_rope_kv_store: write window outside the new tokens");
+  // write_len == 0 with roped_offset > L is legal: a recompute pass whose tokens all lie inside the protected sink writes nothing
+  // (wan/modules/causal_model.py:302-311 with write_start = sink_tokens > local_end: roped_offset = sink - local_start, write_len = 0)
+  LL_REQUIRE(write_len >= 0 && roped_offset >= 0 && (write_len == 0 || roped_offset + write_len <= L), "ll_qk_norm_rope_kv_store: write window outside the new tokens");
   LL_REQUIRE(write_len == 0 || (write_start >= 0 && write_start + write_len <= S), "ll_qk_norm_rope_kv_store: write [%d,+%d) outside cache of %d slots", write_start, write_len, S);
   int rows = B * L;
   if (rows == 0) return LL_OK;

@@ -32,14 +32,15 @@
 template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int lid = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (lid / ntn) * V2_BM, n0 = (lid % ntn) * BN;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn), mt_, nt_;
+  tile_of(lid, ntm, ntn, gm, mt_, nt_);
+  const int m0 = mt_ * V2_BM, n0 = nt_ * BN;
 
   typename Ty<I8>::acc acc[4][4];
 #pragma unroll
@@ -104,14 +105,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
 template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int lid = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (lid / ntn) * V3_BM, n0 = (lid % ntn) * V3_BN;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn), mt_, nt_;
+  tile_of(lid, ntm, ntn, gm, mt_, nt_);
+  const int m0 = mt_ * V3_BM, n0 = nt_ * V3_BN;
 
   typename Ty<I8>::acc acc[4][8];
 #pragma unroll
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict_
 template <int EPI, bool I8, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
   static_assert(WM * WN == 8 && WM * MT * 16 == 256, "8 waves, 256 rows");
   constexpr int BNv = WN * NT * 16, STAGE = (256 + BNv) * ROWB, NB = BNv / 8;   // NB = B pieces of 8 rows per K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -176,8 +178,9 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  int lid = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (lid / ntn) * 256, n0 = (lid % ntn) * BNv;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn), mt_, nt_;
+  tile_of(lid, ntm, ntn, gm, mt_, nt_);
+  const int m0 = mt_ * 256, n0 = nt_ * BNv;
 
   typename Ty<I8>::acc acc[NT][MT];
 #pragma unroll
@@ -269,14 +272,15 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict_
 template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int lid = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (lid / ntn) * V3_BM, n0 = (lid % ntn) * V3_BN;
+  int lid = xcd_remap(blockIdx.x, ntm * ntn), mt_, nt_;
+  tile_of(lid, ntm, ntn, gm, mt_, nt_);
+  const int m0 = mt_ * V3_BM, n0 = nt_ * V3_BN;
 
   typename Ty<I8>::acc acc[4][8];
 #pragma unroll
@@ -335,12 +339,16 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict_
 
 // runtime tuning switches (A/B experiments from tools/kbench; defaults are the shipped configuration)
 static int g_gemm_variant = 0;
+static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
+void ll_set_attn_sk_internal(int v);
 extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return LL_OK; }
+  if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return LL_OK; }
   if (!strcmp(key, "attn_variant")) { ll_set_attn_variant_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
+  if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }
@@ -451,9 +459,12 @@ extern "C" int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap) {
   LL_REQUIRE(out != nullptr && cap > 0, "ll_gemm_plan: needs an output buffer");
   const int v = pick_gemm_variant(M, N);
   const int bn = v == 3 || v == 4 ? 256 : v == 5 ? 192 : v == 6 ? 224 : 128;
+  char walk[48];
+  if (g_gemm_group_m > 1) snprintf(walk, sizeof walk, ", groups of %d m-tiles", g_gemm_group_m);
+  else snprintf(walk, sizeof walk, ", N fastest");
   const char* name = v == 2 ? "gemm_kernel_v2" : v == 3 ? "gemm_kernel_v3" : v == 4 ? "gemm_kernel_v4" : "gemm_kernel_v5";
   int ntm = (M + 255) / 256, ntn = (N + bn - 1) / bn;
-  snprintf(out, (size_t)cap, "%s<%s> tile 256x%d, %d workgroups", name, int8 ? "i8" : "bf16", bn, ntm * ntn);
+  snprintf(out, (size_t)cap, "%s<%s> tile 256x%d, %d workgroups%s", name, int8 ? "i8" : "bf16", bn, ntm * ntn, walk);
   (void)K;
   return LL_OK;
 }
@@ -471,6 +482,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
   int bm = (v3 || v5 || v6) ? 256 : V2_BM, bn = v3 ? V3_BN : v5 ? 192 : v6 ? 224 : BN;
   int ntm = (M + bm - 1) / bm, ntn = (N + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
+  const int gm = g_gemm_group_m;
   size_t lds = v3 ? 2 * V3_STAGE : (v5 || v6) ? 2 * (size_t)(256 + bn) * ROWB : 3 * V2_STAGE;
 #define LAUNCH(E)                                                                                                      \
   do {                                                                                                                 \
@@ -483,10 +495,10 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
       }                                                                                                                \
       if (v5)                                                                                                          \
         hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 2, 4, 8, 3>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
-                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                 \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                 \
       else                                                                                                             \
         hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 4, 2, 4, 7>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
-                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                 \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                 \
     } else if (v4) {                                                                                                   \
       static bool a4 = false;                                                                                          \
       if (!a4) {                                                                                                       \
@@ -494,7 +506,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         a4 = true;                                                                                                     \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v4<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                   \
     } else if (v3) {                                                                                                   \
       static bool a3 = false;                                                                                          \
       if (!a3) {                                                                                                       \
@@ -502,7 +514,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         a3 = true;                                                                                                     \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v3<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                   \
     } else {                                                                                                           \
       static bool a2 = false;                                                                                          \
       if (!a2) {                                                                                                       \
@@ -510,7 +522,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         a2 = true;                                                                                                     \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v2<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, ea);                                                   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                   \
     }                                                                                                                  \
   } while (0)
   switch (epilogue) {

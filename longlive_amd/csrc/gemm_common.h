@@ -116,6 +116,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Workgroup id -> (m-tile, n-tile).  The XCD remap hands every XCD (= every L2) a contiguous range of `lid`s; inside it the
+// tiles are walked in groups of `gm` m-tiles, m fastest: the ~32 workgroups an XCD runs at a time then cover a compact
+// gm x (32 / gm) block of tiles and share gm X panels and 32 / gm W panels through the L2, instead of one X panel and 32
+// different W panels (N fastest, gm <= 1).  PMC, FFN1 4680 x 8960 x 1536 with N fastest: 640 MB of L2-miss traffic per launch
+// against 126 MB algorithmic -- every W panel was fetched once per m-tile (profiles/r02_pmc_shipped.md).
+__device__ __forceinline__ void tile_of(int lid, int ntm, int ntn, int gm, int& mt, int& nt) {
+  if (gm <= 1) {
+    mt = lid / ntn;
+    nt = lid % ntn;
+    return;
+  }
+  int per = gm * ntn;
+  int g = lid / per;
+  int first = g * gm;
+  int gs = ntm - first < gm ? ntm - first : gm;
+  int w = lid - g * per;
+  mt = first + w % gs;
+  nt = w / gs;
+}
+
 template <bool I8>
 __device__ __forceinline__ typename Ty<I8>::acc acc_zero() {
   typename Ty<I8>::acc z = {0, 0, 0, 0};

@@ -295,6 +295,22 @@ def linear_small(x, w, bias, act_in: int = 0, act_out: int = 0):
     return out
 
 
+_attn_ws = {}
+
+
+def attn_workspace(device) -> torch.Tensor:
+    """Scratch for ll_flash_attn's stream-K path (the ABI never allocates): one buffer per device, reused by every launch on
+    the stream (launches on one stream are ordered, and a launch reads only what it wrote itself)."""
+    lib = _lib.load()
+    need = int(lib.ll_flash_attn_workspace_bytes())
+    key = (device.type, device.index)
+    buf = _attn_ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _attn_ws[key] = buf
+    return buf
+
+
 def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None, tag: Optional[str] = None):
     """q [B,Lq,H,128] (contiguous); k,v [B,Sk,H,128]; keys = concatenation of up to two row ranges
     [(start, end), ...] of k/v.  Returns [B,Lq,H,128]."""
@@ -314,13 +330,15 @@ def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None, tag: 
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _lib.load()
+    ws = attn_workspace(q.device)
     t0 = None
     if timer is not None:
         nkeys = (e0 - s0) + (e1 - s1)
         tag = tag or "flash_attn"
         t0 = timer.begin(tag)
     _lib.check(lib.ll_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, H, H * D, H * D,
-                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, _stream()), "ll_flash_attn")
+                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, ws.data_ptr(), ws.numel(), _stream()),
+               "ll_flash_attn")
     if timer is not None:
         timer.end(tag, t0, 4.0 * B * H * Lq * nkeys * D)     # algorithmic FLOPs: QK^T + PV
     return out

@@ -16,7 +16,7 @@ HEADER = open(os.path.join(ROOT, "include", "longlive_hip.h")).read()
 def _declarations():
     body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(ll_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long long|const char\*)\s+(ll_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", body, flags=re.S):
         args = m.group(2).strip()
         decls[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
     return decls
@@ -54,7 +54,8 @@ def test_no_torch_types_in_the_abi():
     (lambda L: L.ll_kv_roll(0, 0, 1, 100, 1536, 5, 90, 20, None), "outside cache"),
     (lambda L: L.ll_qk_norm_rope_kv_store(0, 0, 0, 0, 0, 0, 0, 0, 1, 4680, 1536, 128, 1560, 1023, 18720, 0, 0, 4680, 1e-6, None), "RoPE table"),
     (lambda L: L.ll_qk_norm_rope_kv_store(0, 0, 0, 0, 0, 0, 0, 0, 1, 4680, 1536, 128, 1560, 0, 18720, 18000, 0, 4680, 1e-6, None), "outside cache"),
-    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 0, 0, 0, 0.088, None), "non-empty"),
+    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 0, 0, 0, 0.088, None, 0, None), "non-empty"),
+    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 64, 0, 0, 0.088, None, 4096, None), "workspace"),
     (lambda L: L.ll_linear_small(0, 0, 0, 0, 9, 64, 64, 0, 0, None), "M=9"),
 ])
 def test_invalid_arguments_are_rejected_before_launch(call, needle):

@@ -55,6 +55,7 @@ def test_layernorm_affine_and_rmsnorm(ops, C, rows):
     (2, 2, 4, 6, 2, 5, 24, 0, 48),        # later frames, batch 2
     (1, 2, 3, 5, 12, 959, 15, 15, 15),    # recompute with sink protection: first 15 tokens not written
     (1, 1, 30, 52, 12, 7, 100, 0, 1560),  # real frame geometry
+    (1, 1, 3, 5, 12, 2, 45, 30, 0),       # recompute entirely inside the protected sink: nothing written (config 1, block 1)
 ])
 def test_qk_norm_rope_kv_store(ops, B, F, hp, wp, H, start_frame, ws, ro, wl):
     D = 128
@@ -188,6 +189,54 @@ def test_flash_attn(ops, B, Lq, H, Sk, segs):
     err, oerr = (got - exact).abs().max().item(), (oracle - exact).abs().max().item()
     assert err < 1.2e-2, f"max abs err vs fp64 {err} (oracle's own bf16 path: {oerr})"
     assert rel_l2(got, exact) < 6e-3, (rel_l2(got, exact), rel_l2(oracle, exact))
+
+
+def _set_tuning(key, value):
+    from longlive_amd import _lib
+    _lib.check(_lib.load().ll_set_tuning(key.encode(), int(value)), "ll_set_tuning")
+
+
+@pytest.mark.parametrize("B,Lq,H,Sk,seg,W", [
+    (2, 300, 3, 1500, (0, 1437), 5),      # 12 pairs x 23 tiles over 5 workgroups: whole pairs + head / tail parts, ragged keys
+    (2, 300, 3, 1500, (0, 1437), 40),     # more workgroups than pairs: every pair cut into 3-4 parts (middle parts too)
+    (1, 257, 2, 2000, (37, 1100), 3),     # key range that does not start at slot 0; padded waves in the last q-tile
+    (1, 600, 1, 1100, (0, 1088), 8),      # 3 pairs x 17 tiles over 8 workgroups
+    (1, 64, 1, 1024, (0, 1024), 16),      # one pair, one tile per workgroup
+    (1, 520, 2, 1300, (0, 1300), 400),    # more workgroups than tile units: some workgroups have no work
+])
+def test_flash_attn_stream_k(ops, B, Lq, H, Sk, seg, W):
+    """The stream-K cut (key-tile ranges over a fixed number of workgroups + log-sum-exp merge of the parts) at sizes the
+    fp64 reference handles in full, with the workgroup count forced so that every kind of part occurs."""
+    q = hn("aq", (B, Lq, H, 128))
+    k = hn("ak", (B, Sk, H, 128))
+    v = hn("av", (B, Sk, H, 128), 0.7)
+    exact = R.attention_exact(q, k[:, seg[0]:seg[1]], v[:, seg[0]:seg[1]])
+    try:
+        _set_tuning("attn_sk_wgs", W)
+        got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
+        _set_tuning("attn_sk_wgs", -1)
+        base = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
+    finally:
+        _set_tuning("attn_sk_wgs", -1)
+    err, berr = (got.double() - exact).abs().max().item(), (base.double() - exact).abs().max().item()
+    assert err < 1.2e-2 and rel_l2(got, exact) < 6e-3, (err, berr, rel_l2(got, exact))
+    assert (got.float() - base.float()).abs().max().item() < 8e-3
+    assert err < 2 * berr + 1e-3, f"stream-K max err {err} vs unsplit kernel {berr}"
+
+
+def test_flash_attn_stream_k_rescale_across_parts(ops):
+    """A spiked key in the LAST part of a split pair: the merge must rescale the earlier parts by 2^(c (m_i - M))."""
+    B, Lq, H, Sk = 1, 64, 1, 2048
+    q, k, v = hn("sq", (B, Lq, H, 128)), hn("sk", (B, Sk, H, 128)), hn("sv", (B, Sk, H, 128))
+    k[0, 2040, 0] = (q[0, 5, 0].float() * 3).to(bf)      # huge score for query 5 in the last tile
+    k[0, 3, 0] = (q[0, 9, 0].float() * 3).to(bf)         # and for query 9 in the first tile
+    exact = R.attention_exact(q, k, v)
+    try:
+        _set_tuning("attn_sk_wgs", 4)
+        got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [(0, Sk)]).cpu().double()
+    finally:
+        _set_tuning("attn_sk_wgs", -1)
+    assert (got - exact).abs().max().item() < 2e-2
 
 
 def test_flash_attn_online_softmax_rescale(ops):

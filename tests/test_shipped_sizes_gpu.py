@@ -43,20 +43,31 @@ def test_flash_attn_production_grids(Lq):
     q = synth.hash_normal(201, f"q{Lq}", (1, Lq, H, D), device=DEV).to(bf)
     k = synth.hash_normal(202, "k", (1, Lk, H, D), device=DEV).to(bf)
     v = (0.7 * synth.hash_normal(203, "v", (1, Lk, H, D), device=DEV)).to(bf)
+    from longlive_amd import _lib
+    import ctypes as C
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.load().ll_flash_attn_plan(Lq, H, 1, Lk, 0, 1, 1, buf, 256), "plan")
+    assert b"flash_attn_pipe_kernel<8, 1>" in buf.value, buf.value     # the shipped launch: one workgroup per (head, q-tile) pair
     try:
         _tuning("attn_xcd", 1)
-        got = ops.flash_attn(q, k, v, [(0, Lk)])
+        got = ops.flash_attn(q, k, v, [(0, Lk)])                    # shipped: 228 / 888 workgroups, XCD-aware placement
         _tuning("attn_xcd", 0)
         got0 = ops.flash_attn(q, k, v, [(0, Lk)])
+        _tuning("attn_sk_wgs", 0)              # opt-in stream-K form: 256 workgroups x equal key-tile runs + merge
+        sk0 = ops.flash_attn(q, k, v, [(0, Lk)])
+        _tuning("attn_xcd", 1)
+        sk = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_variant", 0)             # plain kernel: grid (q-tile, head, batch), no remap, no pipelining
         plain = ops.flash_attn(q, k, v, [(0, Lk)])
     finally:
         _tuning("attn_xcd", 1)
         _tuning("attn_variant", 2)
-    assert torch.equal(got, got0), "XCD-aware workgroup placement must not change a single bit"
+        _tuning("attn_sk_wgs", -1)
+    assert torch.equal(got, got0) and torch.equal(sk, sk0), "XCD-aware workgroup placement must not change a single bit"
     # every element: a wrong (head, q-tile) mapping or a dropped key tile is an O(1) error, far above two kernels' rounding
     d = (got.float() - plain.float()).abs()
     assert d.max().item() < 8e-3, d.max().item()
+    assert (sk.float() - plain.float()).abs().max().item() < 8e-3
     # sampled rows, exact: two rows of every (head, 256-row q-tile) workgroup, in different waves / lane halves; plus the
     # first and last rows
     nqt = (Lq + 255) // 256

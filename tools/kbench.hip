@@ -148,12 +148,25 @@ static void bench_gemm_i8(const char* name, int M, int N, int K, int iters) {
   hipFree(xq); hipFree(wq); hipFree(sx); hipFree(sw);
 }
 
+static void* g_ws = nullptr;
+static long long g_ws_bytes = 0;
+static void ensure_ws() {
+  long long need = ll_flash_attn_workspace_bytes();
+  if (getenv("KBENCH_NO_WS")) { g_ws = nullptr; g_ws_bytes = 0; return; }
+  if (need > g_ws_bytes) {
+    if (g_ws) CK(hipFree(g_ws));
+    CK(hipMalloc(&g_ws, need));
+    g_ws_bytes = need;
+  }
+}
+
 static void bench_attn(const char* name, int Lq, int H, int Sk, int n0, int iters) {
+  ensure_ws();
   Buf q((size_t)Lq * H * 128, 1.0f), k((size_t)Sk * H * 128, 1.0f), v((size_t)Sk * H * 128, 0.7f), o((size_t)Lq * H * 128, 0.f);
   hipStream_t s = 0;
   float scale = 1.0f / sqrtf(128.f);
   auto fn = [&]() {
-    LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, Lq, H, H * 128, H * 128, H * 128, (long long)Sk * H * 128, 0, n0, 0, 0, scale, s));
+    LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, Lq, H, H * 128, H * 128, H * 128, (long long)Sk * H * 128, 0, n0, 0, 0, scale, g_ws, g_ws_bytes, s));
   };
   double ms = time_ms(s, iters, fn);
   o.pull();
@@ -217,13 +230,15 @@ static void bench_shipped(int iters) {
   {
     Buf q((size_t)L * C, 1.0f), k((size_t)S * C, 1.0f), v((size_t)S * C, 0.7f), o((size_t)L * C, 0.f);
     float scale = 1.0f / sqrtf(128.f);
-    double ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, L, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, s)); });
-    LL(ll_flash_attn_plan(L, H, 1, S, 0, 1, plan, sizeof plan));
+    ensure_ws();
+    double ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, L, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, g_ws, g_ws_bytes, s)); });
+    LL(ll_flash_attn_plan(L, H, 1, S, 0, 1, g_ws != nullptr, plan, sizeof plan));
     double fl = 4.0 * L * (double)S * 128 * H;
     printf("%-10s %-60.60s %8.1f us %7.1f TFLOP/s\n", "attn_self", plan, ms * 1e3, fl / (ms * 1e-3) / 1e12);
-    work_line("flash_attn_self", "flash_attn_pipe_kernel<8, 1>", fl, 2.0 * (2.0 * L * C + 2.0 * S * C), ms * 1e3, "mfma");
+    work_line("flash_attn_self", strstr(plan, "flash_attn_sk") ? "flash_attn_sk_kernel<8>" : "flash_attn_pipe_kernel<8, 1>", fl,
+              2.0 * (2.0 * L * C + 2.0 * S * C), ms * 1e3, "mfma");
     Buf kc((size_t)512 * C, 1.0f), vc((size_t)512 * C, 0.7f);
-    ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, kc.d, vc.d, o.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, s)); });
+    ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, kc.d, vc.d, o.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, g_ws, g_ws_bytes, s)); });
     fl = 4.0 * L * 512.0 * 128 * H;
     printf("%-10s %-60.60s %8.1f us %7.1f TFLOP/s\n", "attn_cross", "flash_attn_pipe_kernel<8, 0> (512 text keys)", ms * 1e3, fl / (ms * 1e-3) / 1e12);
     work_line("flash_attn_cross", "flash_attn_pipe_kernel<8, 0>", fl, 2.0 * (2.0 * L * C + 2.0 * 512 * C), ms * 1e3, "mfma");

@@ -76,7 +76,9 @@ int main(int argc, char** argv) {
     auto* v = (ll_bf16*)dalloc((size_t)Lk * H * 128 * 2, 0.7f);
     auto* o = (ll_bf16*)dalloc((size_t)M * H * 128 * 2, 0.f);
     float scale = 1.0f / sqrtf(128.f);
-    fn = [=]() { LL(ll_flash_attn(q, k, v, o, 1, M, H, H * 128, H * 128, H * 128, (long long)Lk * H * 128, 0, Lk, 0, 0, scale, s)); };
+    long long ws_bytes = getenv("KENERGY_NO_WS") ? 0 : ll_flash_attn_workspace_bytes();
+    void* ws = ws_bytes ? dalloc((size_t)ws_bytes, 0.f) : nullptr;
+    fn = [=]() { LL(ll_flash_attn(q, k, v, o, 1, M, H, H * 128, H * 128, H * 128, (long long)Lk * H * 128, 0, Lk, 0, 0, scale, ws, ws_bytes, s)); };
     flops = 4.0 * M * Lk * H * 128;
   } else {
     LL(ll_set_tuning("gemm_variant", variant));
