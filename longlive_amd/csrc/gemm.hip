@@ -32,7 +32,7 @@
 template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, int lds_epi, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +92,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
     __builtin_amdgcn_s_setprio(0);
     slot = slot == 2 ? 0 : slot + 1;
   }
-  gemm_epilogue<EPI, I8, 4, 4>(acc, Y, M, N, ldo, m0 + wm * 64, n0 + wn * 64, fr, fg, ea);
+  if (lds_epi) {
+    __builtin_amdgcn_s_barrier();      // every wave has read its last K-step's fragments: the ring is free
+    gemm_epilogue_lds<EPI, I8, 4, 4>(acc, Y, M, N, ldo, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (64 * EPI_ROW_BYTES(4)), ea);
+  } else {
+    gemm_epilogue<EPI, I8, 4, 4>(acc, Y, M, N, ldo, m0 + wm * 64, n0 + wn * 64, fr, fg, ea);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
 template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, int lds_epi, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v3(const char* __restrict_
 template <int EPI, bool I8, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, int lds_epi, EpiArgs ea) {
   static_assert(WM * WN == 8 && WM * MT * 16 == 256, "8 waves, 256 rows");
   constexpr int BNv = WN * NT * 16, STAGE = (256 + BNv) * ROWB, NB = BNv / 8;   // NB = B pieces of 8 rows per K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -227,7 +232,13 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict_
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  gemm_epilogue<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, fr, fg, ea);
+  if (lds_epi) {
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_lds<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, lane,
+                                       smem + wave * (MT * 16 * EPI_ROW_BYTES(NT)), ea);
+  } else {
+    gemm_epilogue<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, fr, fg, ea);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict_
 template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
-                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, EpiArgs ea) {
+                                                         size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, int lds_epi, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -339,6 +350,10 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict_
 
 // runtime tuning switches (A/B experiments from tools/kbench; defaults are the shipped configuration)
 static int g_gemm_variant = 0;
+static int g_gemm_variant_wide = 0;  // like gemm_variant, but only for N >= 4096 (QKV, FFN1): A/B of the wide tilings alone
+// 1: epilogue staged through LDS (whole-line residual loads / stores) in the v2 / v5 tilings, except the GELU epilogue, whose
+// register form measured 1.6 % faster (FFN1 127.2 vs 129.3 us; everything else 1.5-11 % faster staged); 2: all; 0: none
+static int g_gemm_lds_epi = 1;
 static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
@@ -346,6 +361,8 @@ void ll_set_attn_sk_internal(int v);
 extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return LL_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return LL_OK; }
+  if (!strcmp(key, "gemm_variant_wide")) { g_gemm_variant_wide = value; return LL_OK; }
+  if (!strcmp(key, "gemm_lds_epi")) { g_gemm_lds_epi = value; return LL_OK; }
   if (!strcmp(key, "attn_variant")) { ll_set_attn_variant_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
@@ -434,6 +451,7 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const bf16* __restri
 // more per flop than the 128-row ones; a tile count below the CU count is one round of whatever fills most CUs).
 static int pick_gemm_variant(int M, int N) {
   int variant = g_gemm_variant;
+  if (N >= 4096 && g_gemm_variant_wide >= 2 && g_gemm_variant_wide <= 6) variant = g_gemm_variant_wide;
   if (variant < 2 || variant > 6) {
     const int ntm_ = (M + 255) / 256;
     auto cost = [&](int bn, double eff) {
@@ -483,6 +501,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
   int ntm = (M + bm - 1) / bm, ntn = (N + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
   const int gm = g_gemm_group_m;
+  const int lds_epi = g_gemm_lds_epi == 2 || (g_gemm_lds_epi == 1 && epilogue != LL_EPI_BIAS_GELU);
   size_t lds = v3 ? 2 * V3_STAGE : (v5 || v6) ? 2 * (size_t)(256 + bn) * ROWB : 3 * V2_STAGE;
 #define LAUNCH(E)                                                                                                      \
   do {                                                                                                                 \
@@ -495,10 +514,10 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
       }                                                                                                                \
       if (v5)                                                                                                          \
         hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 2, 4, 8, 3>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
-                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                 \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                 \
       else                                                                                                             \
         hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 4, 2, 4, 7>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
-                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                 \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                 \
     } else if (v4) {                                                                                                   \
       static bool a4 = false;                                                                                          \
       if (!a4) {                                                                                                       \
@@ -506,7 +525,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         a4 = true;                                                                                                     \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v4<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                   \
     } else if (v3) {                                                                                                   \
       static bool a3 = false;                                                                                          \
       if (!a3) {                                                                                                       \
@@ -514,7 +533,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         a3 = true;                                                                                                     \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v3<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                   \
     } else {                                                                                                           \
       static bool a2 = false;                                                                                          \
       if (!a2) {                                                                                                       \
@@ -522,7 +541,7 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         a2 = true;                                                                                                     \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v2<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, ea);                                                   \
+                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                   \
     }                                                                                                                  \
   } while (0)
   switch (epilogue) {

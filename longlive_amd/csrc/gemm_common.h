@@ -57,56 +57,169 @@ __device__ __forceinline__ void stage_rows(const char* __restrict__ src, size_t 
 
 // Epilogue: acc[a][b] is the 16x16 MFMA tile (n-tile a, m-tile b); lane holds out[m][n .. n+3] with
 // m = mw + b*16 + (lane & 15), n = nw + a*16 + (lane >> 4)*4.  Rounding points follow the reference's bf16 modules.
+// Every global read of the epilogue -- residual rows, gate vectors, bias, int8 scales -- is issued up front, unconditionally,
+// from clamped addresses (rows past M re-read row M-1, columns past N re-read the last 4 columns; never stored), so the
+// MT x NTL residual loads of a lane are ONE round trip.  Guarded by `if (m >= M) continue` they were MT dependent round
+// trips of ~1 us each at the end of every O / cross-O / FFN2 launch.
 template <int EPI, bool I8, int NTL, int MT>
 __device__ __forceinline__ void gemm_epilogue(typename Ty<I8>::acc (&acc)[NTL][MT], bf16* __restrict__ Y, int M, int N,
                                               int ldo, int mw, int nw, int fr, int fg, const EpiArgs& ea) {
+  constexpr bool RES = (EPI == LL_EPI_BIAS_GATE_RES || EPI == LL_EPI_BIAS_RES);
+  constexpr bool GATE = (EPI == LL_EPI_BIAS_GATE_RES);
+  int nc[NTL];
+  bf16x4 bv[NTL], gm[GATE ? NTL : 1];
+  f32x4 swv[I8 ? NTL : 1];
 #pragma unroll
-  for (int b = 0; b < MT; ++b) {
-    int m = mw + b * 16 + fr;
-    if (m >= M) continue;
-    const bf16* gate_e = nullptr;
-    if (EPI == LL_EPI_BIAS_GATE_RES) {
-      int bb = m / ea.rows_per_batch, f = (m % ea.rows_per_batch) / ea.frame_len;
-      gate_e = ea.e + ((size_t)(bb * ea.F + f) * ea.nmod + ea.gate_idx) * N;
+  for (int a = 0; a < NTL; ++a) {
+    int n = nw + a * 16 + fg * 4;
+    nc[a] = n < N ? n : N - 4;
+    bv[a] = *reinterpret_cast<const bf16x4*>(ea.bias + nc[a]);
+    if (GATE) gm[a] = *reinterpret_cast<const bf16x4*>(ea.mod + (size_t)ea.gate_idx * N + nc[a]);
+    if (I8) swv[a] = *reinterpret_cast<const f32x4*>(ea.sw + nc[a]);
+  }
+  // m-subtiles per batch of loads: <= 16 (m, n) subtiles in flight per lane, or the wide tilings' epilogues spill
+  constexpr int CH = NTL > 4 ? 2 : (MT > 4 ? 4 : MT);
+  static_assert(MT % CH == 0, "epilogue batches must tile MT");
+#pragma unroll
+  for (int b0 = 0; b0 < MT; b0 += CH) {
+    bf16x4 rv[RES ? CH : 1][RES ? NTL : 1], ge[GATE ? CH : 1][GATE ? NTL : 1];
+    float sxm[I8 ? CH : 1];
+#pragma unroll
+    for (int bi = 0; bi < CH; ++bi) {
+      int m = mw + (b0 + bi) * 16 + fr;
+      int mc = m < M ? m : M - 1;
+      if (I8) sxm[bi] = ea.sx[mc];
+      const bf16* gate_e = nullptr;
+      if (GATE) {
+        int bb = mc / ea.rows_per_batch, f = (mc % ea.rows_per_batch) / ea.frame_len;
+        gate_e = ea.e + ((size_t)(bb * ea.F + f) * ea.nmod + ea.gate_idx) * N;
+      }
+#pragma unroll
+      for (int a = 0; a < NTL; ++a) {
+        if (RES) rv[bi][a] = *reinterpret_cast<const bf16x4*>(ea.res + (size_t)mc * ldo + nc[a]);
+        if (GATE) ge[bi][a] = *reinterpret_cast<const bf16x4*>(gate_e + nc[a]);
+      }
     }
-    float sxm = 1.0f;
-    if (I8) sxm = ea.sx[m];
 #pragma unroll
-    for (int a = 0; a < NTL; ++a) {
-      int n = nw + a * 16 + fg * 4;
-      if (n >= N) continue;
-      bf16x4 bv = *reinterpret_cast<const bf16x4*>(ea.bias + n);
-      float v[4];
+    for (int bi = 0; bi < CH; ++bi) {
+      const int b = b0 + bi;
+      int m = mw + b * 16 + fr;
+#pragma unroll
+      for (int a = 0; a < NTL; ++a) {
+        int n = nw + a * 16 + fg * 4;
+        float v[4];
+        if (I8) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = rbf((float)acc[a][b][j] * (sxm[bi] * swv[a][j]) + (float)bv[a][j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = rbf((float)acc[a][b][j] + (float)bv[a][j]);
+        }
+        bf16x4 o;
+        if (EPI == LL_EPI_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        } else if (EPI == LL_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)gelu_tanh(v[j]);
+        } else if (EPI == LL_EPI_BIAS_GATE_RES) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float g = rbf((float)gm[a][j] + (float)ge[bi][a][j]);
+            o[j] = (bf16)((float)rv[bi][a][j] + rbf(v[j] * g));
+          }
+        } else {  // LL_EPI_BIAS_RES
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)rv[bi][a][j] + v[j]);
+        }
+        if (m < M && n < N) *reinterpret_cast<bf16x4*>(Y + (size_t)m * ldo + n) = o;
+      }
+    }
+  }
+}
+
+// LDS-staged form of the epilogue (the GEMM kernels' K-loop rings are free by then): every wave parks its bias(+GELU)-ed
+// bf16 tile in a private LDS region in the MFMA lane layout (8 bytes per lane and subtile), reads it back ROW-contiguous
+// (16 bytes per lane, a row's NTL*32 bytes on consecutive lanes) and does the residual / gate arithmetic there, so that
+// residual loads and output stores are whole 128-byte lines (1 KiB per wave instruction) instead of 32-byte row slivers over
+// 16 rows: half the store instructions, a quarter of the touched lines per instruction.  Same values, same rounding points.
+// `ep` = this wave's region, EPI_ROW_BYTES(NTL) bytes per row, MT*16 rows; the caller has passed a workgroup barrier after the
+// last K-step's LDS reads.
+#define EPI_ROW_BYTES(NTL) ((NTL) * 32 + 16)
+template <int EPI, bool I8, int NTL, int MT>
+__device__ __forceinline__ void gemm_epilogue_lds(typename Ty<I8>::acc (&acc)[NTL][MT], bf16* __restrict__ Y, int M, int N,
+                                                  int ldo, int mw, int nw, int lane, char* __restrict__ ep, const EpiArgs& ea) {
+  constexpr bool RES = (EPI == LL_EPI_BIAS_GATE_RES || EPI == LL_EPI_BIAS_RES);
+  constexpr bool GATE = (EPI == LL_EPI_BIAS_GATE_RES);
+  constexpr int RS = EPI_ROW_BYTES(NTL), CP = NTL * 2, R = MT * 16, NIT = R * CP / 64;
+  static_assert(R * CP % 64 == 0, "the wave tile must be a whole number of 64-lane row passes");
+  const int fr = lane & 15, fg = lane >> 4;
+  // ---- pass 1 (MFMA layout): v = bf16(acc [* scales] + bias) [GELU] -> LDS
+#pragma unroll
+  for (int a = 0; a < NTL; ++a) {
+    int n = nw + a * 16 + fg * 4;
+    int ncl = n < N ? n : N - 4;
+    bf16x4 bv = *reinterpret_cast<const bf16x4*>(ea.bias + ncl);
+    f32x4 swv = {1.f, 1.f, 1.f, 1.f};
+    if (I8) swv = *reinterpret_cast<const f32x4*>(ea.sw + ncl);
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      float sxm = 1.0f;
       if (I8) {
-        f32x4 swv = *reinterpret_cast<const f32x4*>(ea.sw + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rbf((float)acc[a][b][j] * (sxm * swv[j]) + (float)bv[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = rbf((float)acc[a][b][j] + (float)bv[j]);
+        int m = mw + b * 16 + fr;
+        sxm = ea.sx[m < M ? m : M - 1];
       }
       bf16x4 o;
-      if (EPI == LL_EPI_BIAS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
-      } else if (EPI == LL_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)gelu_tanh(v[j]);
-      } else if (EPI == LL_EPI_BIAS_GATE_RES) {
-        bf16x4 ge = *reinterpret_cast<const bf16x4*>(gate_e + n);
-        bf16x4 gm = *reinterpret_cast<const bf16x4*>(ea.mod + (size_t)ea.gate_idx * N + n);
-        bf16x4 rv = *reinterpret_cast<const bf16x4*>(ea.res + (size_t)m * ldo + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float g = rbf((float)gm[j] + (float)ge[j]);
-          o[j] = (bf16)((float)rv[j] + rbf(v[j] * g));
-        }
-      } else {  // LL_EPI_BIAS_RES
-        bf16x4 rv = *reinterpret_cast<const bf16x4*>(ea.res + (size_t)m * ldo + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)rv[j] + v[j]);
+      for (int j = 0; j < 4; ++j) {
+        float v = I8 ? rbf((float)acc[a][b][j] * (sxm * swv[j]) + (float)bv[j]) : rbf((float)acc[a][b][j] + (float)bv[j]);
+        o[j] = (bf16)(EPI == LL_EPI_BIAS_GELU ? gelu_tanh(v) : v);
       }
-      *reinterpret_cast<bf16x4*>(Y + (size_t)m * ldo + n) = o;
+      *reinterpret_cast<bf16x4*>(ep + (b * 16 + fr) * RS + (a * 16 + fg * 4) * 2) = o;
+    }
+  }
+  // ---- pass 2 (row layout): chunk q = it*64 + lane -> (row q / CP, 16-byte chunk q % CP); loads of PC iterations up front
+  constexpr int PC = GATE ? 4 : 8;
+#pragma unroll
+  for (int it0 = 0; it0 < NIT; it0 += PC) {
+    int row[PC], col[PC];
+    bool ok[PC];
+    bf16x8 rv[RES ? PC : 1], ge[GATE ? PC : 1], gm[GATE ? PC : 1];
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      if (it0 + i >= NIT) continue;
+      int q = (it0 + i) * 64 + lane;
+      int rr = q / CP, ch = q - rr * CP;
+      row[i] = rr;
+      col[i] = ch * 8;
+      int m = mw + rr, n = nw + ch * 8;
+      ok[i] = m < M && n < N;
+      int mc = m < M ? m : M - 1, ncl = n < N ? n : N - 8;
+      if (RES) rv[i] = *reinterpret_cast<const bf16x8*>(ea.res + (size_t)mc * ldo + ncl);
+      if (GATE) {
+        int bb = mc / ea.rows_per_batch, f = (mc % ea.rows_per_batch) / ea.frame_len;
+        ge[i] = *reinterpret_cast<const bf16x8*>(ea.e + ((size_t)(bb * ea.F + f) * ea.nmod + ea.gate_idx) * N + ncl);
+        gm[i] = *reinterpret_cast<const bf16x8*>(ea.mod + (size_t)ea.gate_idx * N + ncl);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PC; ++i) {
+      if (it0 + i >= NIT) continue;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(ep + row[i] * RS + col[i] * 2);
+      bf16x8 o;
+      if (GATE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float g = rbf((float)gm[i][j] + (float)ge[i][j]);
+          o[j] = (bf16)((float)rv[i][j] + rbf((float)v[j] * g));
+        }
+      } else if (RES) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)rv[i][j] + (float)v[j]);
+      } else {
+        o = v;
+      }
+      if (ok[i]) *reinterpret_cast<bf16x8*>(Y + (size_t)(mw + row[i]) * ldo + nw + col[i]) = o;
     }
   }
 }
