@@ -63,6 +63,13 @@ int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg
 int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf16* mod, int nmod, int shift_idx,
                    int scale_idx, int B, int L, int C, int F, float eps, ll_stream stream);
 
+/* out[l, bf, i, :] = bf16(mods[l, i, :] + e[bf, i, :]) for all layers l of one forward: `e = modulation + e0`
+ * (wan/modules/causal_model.py:440) evaluated once per (layer, frame) instead of once per token row.  A layer's slice
+ * out[l] [B*F, nmod, C] may be passed as `e` with mod = NULL to ll_ln_modulate / ll_ln_modulate_q8 and to the gate-residual
+ * epilogue of ll_gemm_bf16 / ll_gemm_w8a8: same values, two vector loads and six operations per element fewer. */
+int ll_modulation_table(const ll_bf16* e, const ll_bf16* mods, ll_bf16* out, int num_layers, int BF, int nmod, int C,
+                        ll_stream stream);
+
 /* out = LayerNorm(x) * w + b  (norm3, wan/modules/causal_model.py:397-399,460; wan/modules/model.py:89-99). */
 int ll_layernorm_affine(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int rows, int C,
                         float eps, ll_stream stream);
@@ -102,7 +109,8 @@ int ll_kv_roll(ll_bf16* cache_k, ll_bf16* cache_v, int B, int S, int C, int dst,
  * Replaces nn.Linear q/k/v/o, ffn.0/ffn.2, text_embedding, patch_embedding (as GEMM), head.head
  * (wan/modules/causal_model.py:90-93,406-408,599-603; wan/modules/model.py:172-193).
  * res [M, ldo] may alias out.  For LL_EPI_BIAS_GATE_RES: gate = bf16(mod[gate_idx,:] + e[b, f, gate_idx, :]) with
- * b = row / rows_per_batch, f = (row % rows_per_batch) / frame_len; e [B, F, nmod, N], mod [nmod, N]. */
+ * b = row / rows_per_batch, f = (row % rows_per_batch) / frame_len; e [B, F, nmod, N], mod [nmod, N]; mod = NULL: e already
+ * holds that sum (ll_modulation_table). */
 int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
                  int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod, int nmod,
                  int gate_idx, int rows_per_batch, int frame_len, ll_stream stream);

@@ -263,6 +263,26 @@ __device__ __forceinline__ float xhalf_sum(float x) {
   return a + b;
 }
 
+// Final O^T / l -> bf16 rows.  A lane (r, h) holds, for query r, d = 32 db + 8 g4 + 4 h + (0..3): 16 x 8-byte stores per lane.
+// v_permlane32_swap of the packed words of g4 = k (vdst) and k + 1 (src) hands lanes 0-31 the upper half's group k and lanes
+// 32-63 the lower half's group k + 1: every lane then owns 16 contiguous bytes (d = 32 db + 8 (k + h) .. +7) -> 8 x 16-byte
+// stores, same bytes, same addresses, half the store instructions (the tail of this kernel is store-issue bound).  The swap
+// crosses lanes: it runs with EXEC all ones, only the store is predicated.
+__device__ __forceinline__ void store_o_rows(const f32x16 (&o)[4], float inv, bf16* __restrict__ orow, int h, bool valid) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int kp = 0; kp < 4; kp += 2) {
+      unsigned ax = pack_bf16x2(o[db][4 * kp] * inv, o[db][4 * kp + 1] * inv);
+      unsigned ay = pack_bf16x2(o[db][4 * kp + 2] * inv, o[db][4 * kp + 3] * inv);
+      unsigned bx = pack_bf16x2(o[db][4 * kp + 4] * inv, o[db][4 * kp + 5] * inv);
+      unsigned by = pack_bf16x2(o[db][4 * kp + 6] * inv, o[db][4 * kp + 7] * inv);
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+      if (valid) *reinterpret_cast<uint4*>(orow + 32 * db + 8 * (kp + h)) = make_uint4(ax, ay, bx, by);
+    }
+}
+
 #define PIPE_KSTAGES 2
 #define PIPE_VSTAGES 3
 
@@ -581,19 +601,10 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
 #undef PHASE_B
 #undef PHASE_A_SCHED
 
-  int qr = q0 + r;
-  if (qr < Lq) {
-    float inv = 1.0f / l_run;
-    bf16* op = O + ((size_t)b * Lq + qr) * ldo + head * 128 + 4 * h;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        uint2 w;
-        w.x = pack_bf16x2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
-        w.y = pack_bf16x2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-        *reinterpret_cast<uint2*>(op + 32 * db + 8 * g4) = w;
-      }
+  {
+    const int qr = q0 + r;
+    const int qc = qr < Lq ? qr : Lq - 1;
+    store_o_rows(o, 1.0f / l_run, O + ((size_t)b * Lq + qc) * ldo + head * 128, h, qr < Lq);
   }
 }
 
@@ -825,19 +836,8 @@ __global__ __launch_bounds__(NW * 64, 1) void flash_attn_sk_kernel(const bf16* _
 
     const int qr = q0 + r;
     if (tb == 0 && te == nt) {                           // a whole pair: final output, as the unsplit kernel writes it
-      if (qr < Lq) {
-        float inv = 1.0f / l_run;
-        bf16* op = O + ((size_t)b * Lq + qr) * ldo + head * 128 + 4 * h;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            uint2 w;
-            w.x = pack_bf16x2(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv);
-            w.y = pack_bf16x2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-            *reinterpret_cast<uint2*>(op + 32 * db + 8 * g4) = w;
-          }
-      }
+      const int qc = qr < Lq ? qr : Lq - 1;
+      store_o_rows(o, 1.0f / l_run, O + ((size_t)b * Lq + qc) * ldo + head * 128, h, qr < Lq);
     } else {                                             // a part: the lane image of O^T (fully coalesced 1 KiB stores), m, l
       const int slot = 2 * lid + (tb > 0 ? 0 : 1);
       float* sp = ws + (size_t)slot * SK_SLOT_FLOATS(NW);

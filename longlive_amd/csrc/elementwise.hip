@@ -102,7 +102,10 @@ __device__ __forceinline__ void emit_row(const RowRegs& y, int C, int lane, int 
 // ---------------------------------------------------------------------------------------------------------------
 // LN (no affine) + per-frame modulation.  Rounding points of the reference (bf16 tensors, causal_model.py:445):
 //   y = bf16(LN(x)); s1 = bf16(1 + bf16(mod_s + e_s)); out = bf16(bf16(y * s1) + bf16(mod_t + e_t))
-template <int NCH>
+// PRE: `e` already holds bf16(mod + e) for every chunk (ll_modulation_table, once per forward for all layers): two vector
+// loads and six VALU operations per element less in a kernel that is as much VALU- as HBM-bound (about 16 operations per element
+// at 4.6 waves per SIMD); the values are the ones the unfused form computes, bit for bit.
+template <int NCH, bool PRE>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
                                                           const bf16* __restrict__ e, const bf16* __restrict__ mod,
                                                           int nmod, int shift_idx, int scale_idx, int rows, int L,
@@ -123,13 +126,16 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict
     if (c < C) {
       bf16x8 es = *reinterpret_cast<const bf16x8*>(eb + (size_t)scale_idx * C + c);
       bf16x8 et = *reinterpret_cast<const bf16x8*>(eb + (size_t)shift_idx * C + c);
-      bf16x8 ms = *reinterpret_cast<const bf16x8*>(mod + (size_t)scale_idx * C + c);
-      bf16x8 mt = *reinterpret_cast<const bf16x8*>(mod + (size_t)shift_idx * C + c);
+      bf16x8 ms, mt;
+      if (!PRE) {
+        ms = *reinterpret_cast<const bf16x8*>(mod + (size_t)scale_idx * C + c);
+        mt = *reinterpret_cast<const bf16x8*>(mod + (size_t)shift_idx * C + c);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float y = rbf((r.v[i][j] - mean) * rstd);
-        float s1 = rbf(1.0f + rbf((float)ms[j] + (float)es[j]));
-        float t = rbf((float)mt[j] + (float)et[j]);
+        float s1 = rbf(1.0f + (PRE ? (float)es[j] : rbf((float)ms[j] + (float)es[j])));
+        float t = PRE ? (float)et[j] : rbf((float)mt[j] + (float)et[j]);
         r.v[i][j] = rbf(rbf(y * s1) + t);
       }
     }
@@ -380,6 +386,24 @@ __global__ __launch_bounds__(64) void sigma_lookup_kernel(const float* __restric
   if (lane == 0) out[blockIdx.x] = sigmas[bi];
 }
 
+// out[l][bf][i][:] = bf16(mods[l][i][:] + e[bf][i][:]): the per-frame modulation vectors of ALL layers of one forward
+// (causal_model.py:440: `e = (self.modulation.unsqueeze(1) + e).chunk(6, dim=2)`), computed once instead of once per token row.
+__global__ __launch_bounds__(256) void modulation_table_kernel(const bf16* __restrict__ e, const bf16* __restrict__ mods,
+                                                               bf16* __restrict__ out, int NL, int BF, int nmodC8) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;           // one 16-byte chunk of the output
+  long long total = (long long)NL * BF * nmodC8;
+  if (i >= total) return;
+  int c = (int)(i % nmodC8);
+  int bf = (int)((i / nmodC8) % BF);
+  int l = (int)(i / ((long long)nmodC8 * BF));
+  bf16x8 a = *reinterpret_cast<const bf16x8*>(mods + ((size_t)l * nmodC8 + c) * 8);
+  bf16x8 b = *reinterpret_cast<const bf16x8*>(e + ((size_t)bf * nmodC8 + c) * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] + (float)b[j]);
+  *reinterpret_cast<bf16x8*>(out + (size_t)i * 8) = o;
+}
+
 // ===============================================================================================================
 // host launchers
 #define DISPATCH_NCH(C, CALL)                   \
@@ -402,12 +426,29 @@ static int ln_modulate_launch(const ll_bf16* x, ll_bf16* out, int8_t* q, float* 
   int rows = B * L;
   if (rows == 0) return LL_OK;
   dim3 grid((rows + 3) / 4);
-#define CALL(N)                                                                                                   \
-  hipLaunchKernelGGL(ln_modulate_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, \
-                     (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps, q, qscale)
+#define CALL(N)                                                                                                          \
+  do {                                                                                                                   \
+    if (mod)                                                                                                             \
+      hipLaunchKernelGGL((ln_modulate_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, \
+                         (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps, q, qscale); \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((ln_modulate_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,  \
+                         (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps, q, qscale); \
+  } while (0)
   DISPATCH_NCH(C, CALL);
 #undef CALL
   return ll_check_launch("ll_ln_modulate");
+}
+
+extern "C" int ll_modulation_table(const ll_bf16* e, const ll_bf16* mods, ll_bf16* out, int num_layers, int BF, int nmod, int C,
+                                   ll_stream stream) {
+  LL_REQUIRE(C > 0 && C % 8 == 0 && nmod > 0 && num_layers >= 0 && BF >= 0, "ll_modulation_table: bad shape");
+  long long chunks = (long long)num_layers * BF * nmod * (C / 8);
+  if (chunks == 0) return LL_OK;
+  LL_REQUIRE(chunks < (1LL << 31) * 256, "ll_modulation_table: too large");
+  hipLaunchKernelGGL(modulation_table_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)e, (const bf16*)mods, (bf16*)out, num_layers, BF, nmod * (C / 8));
+  return ll_check_launch("ll_modulation_table");
 }
 
 extern "C" int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf16* mod, int nmod,

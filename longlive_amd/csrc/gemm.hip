@@ -561,7 +561,7 @@ static int check_epilogue(const char* fn, int M, int N, int ldo, int epilogue, c
   LL_REQUIRE(bias != nullptr, "%s: bias is required", fn);
   LL_REQUIRE(epilogue >= 0 && epilogue <= 3, "%s: unknown epilogue %d", fn, epilogue);
   if (epilogue == LL_EPI_BIAS_GATE_RES) {
-    LL_REQUIRE(res && e && mod, "%s: gate-residual epilogue needs res, e and mod", fn);
+    LL_REQUIRE(res && e, "%s: gate-residual epilogue needs res and e (mod may be NULL: e then holds bf16(mod + e))", fn);
     LL_REQUIRE(frame_len > 0 && rows_per_batch > 0 && rows_per_batch % frame_len == 0 && M % rows_per_batch == 0,
                "%s: rows_per_batch=%d / frame_len=%d do not tile M=%d", fn, rows_per_batch, frame_len, M);
     LL_REQUIRE(gate_idx >= 0 && gate_idx < nmod, "%s: gate_idx %d outside nmod %d", fn, gate_idx, nmod);

@@ -74,7 +74,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Ty<I8>::acc (&acc)[NTL][M
     int n = nw + a * 16 + fg * 4;
     nc[a] = n < N ? n : N - 4;
     bv[a] = *reinterpret_cast<const bf16x4*>(ea.bias + nc[a]);
-    if (GATE) gm[a] = *reinterpret_cast<const bf16x4*>(ea.mod + (size_t)ea.gate_idx * N + nc[a]);
+    if (GATE && ea.mod) gm[a] = *reinterpret_cast<const bf16x4*>(ea.mod + (size_t)ea.gate_idx * N + nc[a]);
     if (I8) swv[a] = *reinterpret_cast<const f32x4*>(ea.sw + nc[a]);
   }
   // m-subtiles per batch of loads: <= 16 (m, n) subtiles in flight per lane, or the wide tilings' epilogues spill
@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Ty<I8>::acc (&acc)[NTL][M
         } else if (EPI == LL_EPI_BIAS_GATE_RES) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float g = rbf((float)gm[a][j] + (float)ge[bi][a][j]);
+            float g = ea.mod ? rbf((float)gm[a][j] + (float)ge[bi][a][j]) : (float)ge[bi][a][j];   // mod == NULL: e is bf16(mod + e)
             o[j] = (bf16)((float)rv[bi][a][j] + rbf(v[j] * g));
           }
         } else {  // LL_EPI_BIAS_RES
@@ -146,6 +146,9 @@ __device__ __forceinline__ void gemm_epilogue(typename Ty<I8>::acc (&acc)[NTL][M
 // `ep` = this wave's region, EPI_ROW_BYTES(NTL) bytes per row, MT*16 rows; the caller has passed a workgroup barrier after the
 // last K-step's LDS reads.
 #define EPI_ROW_BYTES(NTL) ((NTL) * 32 + 16)
+
+// (Loading the residual rows at kernel entry instead, 32 registers held across the K-loop, measured no gain: 72.4-72.7 vs
+// 72.4-72.7 frames/s in an interleaved A/B -- the read is short once it is whole lines; not kept.)
 template <int EPI, bool I8, int NTL, int MT>
 __device__ __forceinline__ void gemm_epilogue_lds(typename Ty<I8>::acc (&acc)[NTL][MT], bf16* __restrict__ Y, int M, int N,
                                                   int ldo, int mw, int nw, int lane, char* __restrict__ ep, const EpiArgs& ea) {
@@ -199,7 +202,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(typename Ty<I8>::acc (&acc)[NT
       if (GATE) {
         int bb = mc / ea.rows_per_batch, f = (mc % ea.rows_per_batch) / ea.frame_len;
         ge[i] = *reinterpret_cast<const bf16x8*>(ea.e + ((size_t)(bb * ea.F + f) * ea.nmod + ea.gate_idx) * N + ncl);
-        gm[i] = *reinterpret_cast<const bf16x8*>(ea.mod + (size_t)ea.gate_idx * N + ncl);
+        if (ea.mod) gm[i] = *reinterpret_cast<const bf16x8*>(ea.mod + (size_t)ea.gate_idx * N + ncl);
       }
     }
 #pragma unroll
@@ -210,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(typename Ty<I8>::acc (&acc)[NT
       if (GATE) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float g = rbf((float)gm[i][j] + (float)ge[i][j]);
+          float g = ea.mod ? rbf((float)gm[i][j] + (float)ge[i][j]) : (float)ge[i][j];   // mod == NULL: e is bf16(mod + e)
           o[j] = (bf16)((float)rv[i][j] + rbf((float)v[j] * g));
         }
       } else if (RES) {

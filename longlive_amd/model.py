@@ -190,6 +190,7 @@ class CausalWanModelHIP(nn.Module):
                     d["q_" + name], d["s_" + name] = ops.quantize_rows(w.detach().contiguous())
             P.append(d)
         self._packed = P
+        self._mods = torch.stack([d["mod"] for d in P], 0).contiguous()      # [NL, 6, C] for ops.modulation_table
         self._packed_key = self._param_key()
         return P
 
@@ -269,12 +270,13 @@ class CausalWanModelHIP(nn.Module):
     def block_forward(self, i: int, xs: torch.Tensor, e0: torch.Tensor, ctx: Optional[torch.Tensor], kvc: dict,
                       cac: dict, F: int, grid_hw: Tuple[int, int], current_start: int,
                       sink_recache_after_switch: bool = False, q_buf: Optional[torch.Tensor] = None,
-                      kv_insert_only: bool = False, pk: Optional[dict] = None) -> KVPlan:
+                      kv_insert_only: bool = False, pk: Optional[dict] = None, premod: bool = False) -> KVPlan:
         """CausalWanAttentionBlock.forward (causal_model.py:413-477) for block `i`: updates the residual stream
         xs [B, L, C] IN PLACE (L = F * hp * wp tokens, grid_hw = (hp, wp) tokens per frame) and this layer's KV / cross
         caches, returns the layer's KV plan (the caller commits the end indices after all layers,
         causal_model.py:1061-1062).  e0 [B, F, 6, C]; ctx = embedded text [B, 512, C] (only read when the cross cache is
-        not initialised).  kv_insert_only: stop after the K/V insert."""
+        not initialised).  kv_insert_only: stop after the K/V insert.  premod: `e0` is this layer's slice of
+        ops.modulation_table (modulation already added), as forward_frames passes it."""
         c = self.cfg
         B, L, C = xs.shape
         Hh, D = c.num_heads, c.head_dim
@@ -288,10 +290,11 @@ class CausalWanModelHIP(nn.Module):
         blk = self.blocks[i]
         if pk is None:
             pk = self._pack()[i]
+        mod = None if premod else pk["mod"]
         sa, ca = blk.self_attn, blk.cross_attn
         # --- self attention (causal_model.py:444-456) ---
         q8 = self.quant == "int8"
-        h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 0, 1, F, c.eps)
+        h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 0, 1, F, c.eps)
         qkv = self._lin(h1, pk, "qkv", pk["wqkv"], pk["bqkv"])
         G, E = _kv_state(kvc)
         S = kvc["k"].shape[1]
@@ -306,7 +309,7 @@ class CausalWanModelHIP(nn.Module):
             return plan
         att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
         self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                  mod=pk["mod"], gate_idx=2, rows_per_batch=L, frame_len=fs)
+                  mod=mod, gate_idx=2, rows_per_batch=L, frame_len=fs)
         # --- cross attention (causal_model.py:460; model.py:159-194) ---
         xn = (ops.layernorm_affine_q8 if q8 else ops.layernorm_affine)(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
         qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
@@ -321,10 +324,10 @@ class CausalWanModelHIP(nn.Module):
         atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
         self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
         # --- FFN (causal_model.py:462-468) ---
-        h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, pk["mod"], 3, 4, F, c.eps)
+        h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 3, 4, F, c.eps)
         ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
         self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                  mod=pk["mod"], gate_idx=5, rows_per_batch=L, frame_len=fs)
+                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs)
         return plan
 
     # ---- forward -----------------------------------------------------------------------------------------------
@@ -357,10 +360,11 @@ class CausalWanModelHIP(nn.Module):
         plans: List[KVPlan] = []
         last = len(self.blocks) - 1
         P = self._pack()       # validated against the live parameters once per forward
+        etab = ops.modulation_table(e0, self._mods)      # [NL, B, F, 6, C] = modulation + e0 for every layer, one launch
         for i in range(len(self.blocks)):
-            plans.append(self.block_forward(i, xs, e0, ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp), current_start,
+            plans.append(self.block_forward(i, xs, etab[i], ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp), current_start,
                                             sink_recache_after_switch, q_buf, kv_insert_only=kv_only and i == last,
-                                            pk=P[i]))
+                                            pk=P[i], premod=True))
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)

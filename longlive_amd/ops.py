@@ -80,17 +80,20 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
 
 
 def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float, out=None, tag: str = "ln_modulate"):
-    """x [B,L,C]; e [B,F,nmod,C]; mod [nmod,C] (causal_model.py:445,463-464,506-507)."""
-    _chk(x, "x"); _chk(e, "e"); _chk(mod, "mod")
+    """x [B,L,C]; e [B,F,nmod,C]; mod [nmod,C] (causal_model.py:445,463-464,506-507); mod=None: `e` is a layer's slice of
+    modulation_table(), i.e. already bf16(mod + e)."""
+    _chk(x, "x"); _chk(e, "e")
     B, L, Cc = x.shape
-    nmod = mod.shape[-2]
+    nmod = e.shape[-2]
     assert e.shape == (B, num_frames, nmod, Cc), (e.shape, (B, num_frames, nmod, Cc))
-    assert mod.numel() == nmod * Cc
+    if mod is not None:
+        _chk(mod, "mod")
+        assert mod.numel() == nmod * Cc
     out = torch.empty_like(x) if out is None else _chk(out, "out")
     assert out.shape == x.shape
     lib = _lib.load()
     t0 = _t0(tag)
-    _lib.check(lib.ll_ln_modulate(x.data_ptr(), out.data_ptr(), e.data_ptr(), mod.data_ptr(), nmod, shift_idx,
+    _lib.check(lib.ll_ln_modulate(x.data_ptr(), out.data_ptr(), e.data_ptr(), _ptr(mod), nmod, shift_idx,
                                   scale_idx, B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate")
     _t1(tag, t0, 4.0 * x.numel())                    # read x, write out (bf16)
     return out
@@ -98,18 +101,35 @@ def ln_modulate(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps:
 
 def ln_modulate_q8(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, eps: float, tag: str = "ln_modulate"):
     """ln_modulate emitting (int8 [B,L,C], float32 scale [B*L]) for a following W8A8 GEMM."""
-    _chk(x, "x"); _chk(e, "e"); _chk(mod, "mod")
+    _chk(x, "x"); _chk(e, "e")
     B, L, Cc = x.shape
-    nmod = mod.shape[-2]
-    assert e.shape == (B, num_frames, nmod, Cc) and mod.numel() == nmod * Cc
+    nmod = e.shape[-2]
+    assert e.shape == (B, num_frames, nmod, Cc)
+    if mod is not None:
+        _chk(mod, "mod")
+        assert mod.numel() == nmod * Cc
     q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
     sc = torch.empty(B * L, dtype=torch.float32, device=x.device)
     lib = _lib.load()
     t0 = _t0(tag)
-    _lib.check(lib.ll_ln_modulate_q8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), e.data_ptr(), mod.data_ptr(), nmod,
+    _lib.check(lib.ll_ln_modulate_q8(x.data_ptr(), q.data_ptr(), sc.data_ptr(), e.data_ptr(), _ptr(mod), nmod,
                                      shift_idx, scale_idx, B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate_q8")
     _t1(tag, t0, 3.0 * x.numel())                    # read bf16, write int8
     return q, sc
+
+
+def modulation_table(e, mods):
+    """e [B,F,nmod,C] (per forward), mods [NL,nmod,C] (per layer) -> [NL,B,F,nmod,C] = bf16(mods[l] + e): what every block
+    computes as `self.modulation.unsqueeze(1) + e` (causal_model.py:440), for all layers in one launch."""
+    _chk(e, "e"); _chk(mods, "mods")
+    B, F, nmod, Cc = e.shape
+    NL = mods.shape[0]
+    assert mods.shape == (NL, nmod, Cc), (mods.shape, e.shape)
+    out = torch.empty(NL, B, F, nmod, Cc, dtype=bf16, device=e.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_modulation_table(e.data_ptr(), mods.data_ptr(), out.data_ptr(), NL, B * F, nmod, Cc, _stream()),
+               "ll_modulation_table")
+    return out
 
 
 def layernorm_affine_q8(x, w, b, eps: float):
@@ -216,10 +236,12 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
         _chk(res, "res")
         assert res.numel() == M * N
     if epilogue == EPI_BIAS_GATE_RES:
-        _chk(e, "e"); _chk(mod, "mod")
-        nmod = mod.shape[-2]
-        assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
-        assert e.numel() == (M // frame_len) * nmod * N, (e.shape, M, frame_len)
+        _chk(e, "e")
+        nmod = e.shape[-2]
+        assert e.shape[-1] == N and e.numel() == (M // frame_len) * nmod * N, (e.shape, M, frame_len)
+        if mod is not None:         # None: e already holds bf16(mod + e) (modulation_table)
+            _chk(mod, "mod")
+            assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
     _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
@@ -265,10 +287,12 @@ def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None
         _chk(res, "res")
         assert res.numel() == M * N
     if epilogue == EPI_BIAS_GATE_RES:
-        _chk(e, "e"); _chk(mod, "mod")
-        nmod = mod.shape[-2]
-        assert mod.numel() == nmod * N and e.shape[-1] == N and e.shape[-2] == nmod
-        assert e.numel() == (M // frame_len) * nmod * N
+        _chk(e, "e")
+        nmod = e.shape[-2]
+        assert e.shape[-1] == N and e.numel() == (M // frame_len) * nmod * N
+        if mod is not None:
+            _chk(mod, "mod")
+            assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
     _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),

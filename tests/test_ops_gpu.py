@@ -326,3 +326,28 @@ def test_fused_ln_quantisation_is_bit_identical_to_unfused(ops):
     q1, s1 = ops.layernorm_affine_q8(x, w, b, 1e-6)
     q2, s2 = ops.quantize_rows(ops.layernorm_affine(x, w, b, 1e-6))
     assert torch.equal(q1, q2) and torch.equal(s1, s2)
+
+
+def test_modulation_table_paths_are_bit_identical(ops):
+    """`modulation + e` evaluated once per (layer, frame) by ll_modulation_table and handed to ln_modulate / the gate-residual
+    GEMM epilogue with mod=None gives the bits of the per-row evaluation (same bf16 rounding points)."""
+    B, F, fs, C, NL = 2, 3, 24, 256, 3
+    x = hn("mx", (B, F * fs, C), 1.7, 0.3).to(DEV)
+    e = hn("me", (B, F, 6, C), 0.5).to(DEV)
+    mods = hn("mmods", (NL, 6, C), 0.1).to(DEV)
+    tab = ops.modulation_table(e, mods)
+    assert tab.shape == (NL, B, F, 6, C)
+    assert torch.equal(tab.cpu(), (mods.cpu().view(NL, 1, 1, 6, C) + e.cpu().unsqueeze(0)).to(bf))
+    for l in range(NL):
+        for sh, sc in ((0, 1), (3, 4)):
+            a = ops.ln_modulate(x, e, mods[l], sh, sc, F, 1e-6)
+            b = ops.ln_modulate(x, tab[l], None, sh, sc, F, 1e-6)
+            assert torch.equal(a, b)
+        qa, sa = ops.ln_modulate_q8(x, e, mods[l], 0, 1, F, 1e-6)
+        qb, sb = ops.ln_modulate_q8(x, tab[l], None, 0, 1, F, 1e-6)
+        assert torch.equal(qa, qb) and torch.equal(sa, sb)
+    h = hn("mh", (B, F * fs, 512)).to(DEV)
+    w, bias, res = hn("mw", (C, 512), 1 / 22).to(DEV), hn("mb", (C,), 0.1).to(DEV), hn("mres", (B, F * fs, C)).to(DEV)
+    a = ops.gemm(h, w, bias, ops.EPI_BIAS_GATE_RES, res=res, e=e, mod=mods[1], gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
+    b = ops.gemm(h, w, bias, ops.EPI_BIAS_GATE_RES, res=res, e=tab[1], mod=None, gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
+    assert torch.equal(a, b)
