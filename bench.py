@@ -387,6 +387,10 @@ def run_replica(args, rank, world, local_rank, sync):
     del sd
     quant = None if args.quant == "none" else args.quant
     gen.model.set_quant(quant)
+    if os.environ.get("LL_MODTAB") == "0":                             # kernel A/B only
+        gen.model.use_modulation_table = False
+    if os.environ.get("LL_FUSE_V") == "0":
+        gen.model.fuse_v_insert = False
     pipe = CausalInferencePipeline(_pipe_args(), dev, generator=gen)
     extra_blocks = 0 if (args.no_extras or rank != 0) else 1           # one more steady-state block for the kernels table
     nblocks = args.warmup + args.steps + extra_blocks

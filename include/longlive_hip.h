@@ -93,7 +93,8 @@ int ll_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C
  *   cache_k/v[B, S, C]   rows [write_start, write_start+write_len) receive roped k / v of tokens
  *                        [roped_offset, roped_offset+write_len)
  *   rope_f   [1024, nf, 2] (cos,sin) fp32 for the frame axis, rope_hw [frame_len, nhw, 2] for the (h,w) axes;
- *            nf + nhw = head_dim / 2.  start_frame = current_start / frame_len. */
+ *            nf + nhw = head_dim / 2.  start_frame = current_start / frame_len.
+ *   cache_v may be NULL: V was already inserted by ll_gemm_bf16_qkv / ll_gemm_w8a8_qkv and the v third of qkv is not read. */
 int ll_qk_norm_rope_kv_store(const ll_bf16* qkv, const ll_bf16* wq, const ll_bf16* wk, const float* rope_f,
                              const float* rope_hw, ll_bf16* q_out, ll_bf16* cache_k, ll_bf16* cache_v, int B, int L,
                              int C, int head_dim, int frame_len, int start_frame, int S, int write_start,
@@ -121,6 +122,16 @@ int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf1
 int ll_gemm_w8a8(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias, ll_bf16* out,
                  int M, int N, int K, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,
                  int nmod, int gate_idx, int rows_per_batch, int frame_len, ll_stream stream);
+
+/* The fused q|k|v projection (N = 3 C, LL_EPI_BIAS) with the V third written straight into the KV cache by the GEMM epilogue:
+ * token t of batch b goes to cache_v[b, write_start + (t - roped_offset), :] when 0 <= t - roped_offset < write_len, exactly the
+ * insert of wan/modules/causal_model.py:264-269,302-311 (V is copied unrotated, so the bits are the projection's).  The q and k
+ * thirds land in out[M, ldo]; its v third is left unwritten.  M = B * L.  Saves one write and one read of V per layer. */
+int ll_gemm_bf16_qkv(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx, int ldo,
+                     ll_bf16* cache_v, int B, int L, int S, int write_start, int roped_offset, int write_len, ll_stream stream);
+int ll_gemm_w8a8_qkv(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias, ll_bf16* out,
+                     int M, int N, int K, int ldo, ll_bf16* cache_v, int B, int L, int S, int write_start, int roped_offset,
+                     int write_len, ll_stream stream);
 
 /* Symmetric per-row int8 quantisation: scale[r] = max|x[r,:]| / 127 (1 for an all-zero row), q = rint(x / scale).
  * Per token for activations, per output channel for weights ([N,K] rows), x row stride ldx elements. */

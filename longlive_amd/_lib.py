@@ -31,6 +31,8 @@ SIGNATURES = {
     "ll_kv_roll": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_gemm_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ll_gemm_bf16_qkv": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ll_gemm_w8a8_qkv": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_quantize_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ll_linear_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p, _ll, _p],

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(
   size_t slot = ((size_t)b * S + write_start + wi) * C;
   load_row<NCH>(src + C, C, lane, r);
   norm_rope_store<NCH>(r, wk, C, lane, eps, rf, rhw, nf, half_hd, wr ? cache_k + slot : nullptr);
-  if (wr) {
+  if (wr && cache_v != nullptr) {        // cache_v == NULL: the QKV projection's epilogue has already inserted V (ll_gemm_*_qkv)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int c = (lane + 64 * i) * 8;

@@ -29,7 +29,11 @@
 #define V2_BM 256
 #define V2_STAGE ((V2_BM + BN) * ROWB)   // 48 KiB
 
-template <int EPI, bool I8>
+// STAG: waves 4-7 (the SIMD partners of waves 0-3) run HALF A K-STEP behind: they defer the 16 MFMAs of a tile's second k-half
+// to the start of the next iteration, their fragments waiting in registers across the barrier.  At every barrier release one
+// wave of each SIMD then has matrix work ready while its partner starts with LDS reads, instead of both waiting for reads and
+// then contending for the pipe (MI355X_MICROARCH.md, "two waves that run the same program with one barrier per block").
+template <int EPI, bool I8, bool STAG>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
                                                          size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, int lds_epi, EpiArgs ea) {
@@ -58,40 +62,64 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
 
   const int fr = lane & 15, fg = lane >> 4;
   const bool live = m0 + wm * 64 < M;       // wave-uniform
+  const bool late = STAG && wave >= 4;      // wave-uniform
   int slot = 0;
+#define V2_READ(WF, XF, KS)                                                                      \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
+    int ch_ = (KS) * 4 + fg;                                                                     \
+    int rw = wn * 64 + t * 16 + fr;                                                              \
+    WF[t] = *reinterpret_cast<const frag_t*>(ws + rw * ROWB + ((ch_ ^ (rw & 7)) << 4));          \
+    int rx = wm * 64 + t * 16 + fr;                                                              \
+    XF[t] = *reinterpret_cast<const frag_t*>(xs + rx * ROWB + ((ch_ ^ (rx & 7)) << 4));          \
+  }
+#define V2_MMA(WF, XF)                                                                           \
+  _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                  \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = Ty<I8>::mma(WF[a], XF[b], acc[a][b]);
+  frag_t wd[4], xd[4];                      // STAG: the second k-half's fragments (consumed one barrier later by the late group)
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed; tile kt+1 may be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the deferred fragments have left the slot restaged below
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; slot (kt+2)%3 is no longer being read
-    if (kt + 2 < nk) {
-      int s2 = slot + 2;
-      s2 = s2 >= 3 ? s2 - 3 : s2;
-      stage(kt + 2, s2);
-    }
+    const bool do_stage = kt + 2 < nk && !(lds_epi & 0x100);          // (0x100: timing experiment, results invalid)
+    int s2 = slot + 2;
+    s2 = s2 >= 3 ? s2 - 3 : s2;
+    if (do_stage && !late) stage(kt + 2, s2);          // STAG: the late group issues its share mid-iteration (below), so that
+                                                        // the two waves of a SIMD are never both busy issuing LDS-DMA pieces
     const char* xs = smem + slot * V2_STAGE;
     const char* ws = xs + V2_BM * ROWB;
-    if (!live) { slot = slot == 2 ? 0 : slot + 1; continue; }   // rows past M (last m-tile): stage and sync only -- the chip
-                                                                // runs at its power cap, idle matrix pipes are speed elsewhere
+    if (!live || (lds_epi & 0x200)) {   // rows past M (last m-tile): stage and sync only -- the chip runs at its power cap,
+      if (do_stage && late) stage(kt + 2, s2);                  // idle matrix pipes are speed elsewhere
+      slot = slot == 2 ? 0 : slot + 1;
+      continue;
+    }
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    if (STAG) {
+      if (late && kt > 0) { V2_MMA(wd, xd); }
       frag_t wf[4], xf[4];
-      int ch = ks * 4 + fg;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        int rw = wn * 64 + t * 16 + fr;
-        wf[t] = *reinterpret_cast<const frag_t*>(ws + rw * ROWB + ((ch ^ (rw & 7)) << 4));
-        int rx = wm * 64 + t * 16 + fr;
-        xf[t] = *reinterpret_cast<const frag_t*>(xs + rx * ROWB + ((ch ^ (rx & 7)) << 4));
+      V2_READ(wf, xf, 0);
+      V2_MMA(wf, xf);
+      if (late) {
+        __builtin_amdgcn_s_setprio(0);
+        if (do_stage) stage(kt + 2, s2);
+        __builtin_amdgcn_s_setprio(1);
       }
+      V2_READ(wd, xd, 1);
+      if (!late) { V2_MMA(wd, xd); }
+    } else {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = Ty<I8>::mma(wf[a], xf[b], acc[a][b]);
+      for (int ks = 0; ks < 2; ++ks) {
+        frag_t wf[4], xf[4];
+        V2_READ(wf, xf, ks);
+        V2_MMA(wf, xf);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     slot = slot == 2 ? 0 : slot + 1;
   }
+  if (STAG && late && live && nk > 0) { V2_MMA(wd, xd); }
+#undef V2_READ
+#undef V2_MMA
   if (lds_epi) {
     __builtin_amdgcn_s_barrier();      // every wave has read its last K-step's fragments: the ring is free
     gemm_epilogue_lds<EPI, I8, 4, 4>(acc, Y, M, N, ldo, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * (64 * EPI_ROW_BYTES(4)), ea);
@@ -354,6 +382,7 @@ static int g_gemm_variant_wide = 0;  // like gemm_variant, but only for N >= 409
 // 1: epilogue staged through LDS (whole-line residual loads / stores) in the v2 / v5 tilings, except the GELU epilogue, whose
 // register form measured 1.6 % faster (FFN1 127.2 vs 129.3 us; everything else 1.5-11 % faster staged); 2: all; 0: none
 static int g_gemm_lds_epi = 1;
+static int g_gemm_stagger = 0;       // 1: 256x128 tiling with waves 4-7 half a K-step behind (gemm_kernel_v2<.., true>)
 static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
@@ -363,6 +392,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return LL_OK; }
   if (!strcmp(key, "gemm_variant_wide")) { g_gemm_variant_wide = value; return LL_OK; }
   if (!strcmp(key, "gemm_lds_epi")) { g_gemm_lds_epi = value; return LL_OK; }
+  if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return LL_OK; }
   if (!strcmp(key, "attn_variant")) { ll_set_attn_variant_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
@@ -501,7 +531,8 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
   int ntm = (M + bm - 1) / bm, ntn = (N + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
   const int gm = g_gemm_group_m;
-  const int lds_epi = g_gemm_lds_epi == 2 || (g_gemm_lds_epi == 1 && epilogue != LL_EPI_BIAS_GELU);
+  const int lds_epi = ((g_gemm_lds_epi & 3) == 2 || ((g_gemm_lds_epi & 3) == 1 && epilogue != LL_EPI_BIAS_GELU) ? 1 : 0) |
+                      (g_gemm_lds_epi & 0x300);   // 0x100 / 0x200: timing experiments (no in-loop staging / no compute), results invalid
   size_t lds = v3 ? 2 * V3_STAGE : (v5 || v6) ? 2 * (size_t)(256 + bn) * ROWB : 3 * V2_STAGE;
 #define LAUNCH(E)                                                                                                      \
   do {                                                                                                                 \
@@ -537,11 +568,16 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
     } else {                                                                                                           \
       static bool a2 = false;                                                                                          \
       if (!a2) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<E, I8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<E, I8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         a2 = true;                                                                                                     \
       }                                                                                                                \
-      hipLaunchKernelGGL((gemm_kernel_v2<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
-                         xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                   \
+      if (g_gemm_stagger)                                                                                              \
+        hipLaunchKernelGGL((gemm_kernel_v2<E, I8, true>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                    \
+      else                                                                                                             \
+        hipLaunchKernelGGL((gemm_kernel_v2<E, I8, false>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
+                           xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                    \
     }                                                                                                                  \
   } while (0)
   switch (epilogue) {
@@ -597,6 +633,54 @@ extern "C" int ll_gemm_w8a8(const int8_t* xq, const float* sx, const int8_t* wq,
              rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
   launch_gemm<true>(xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, epilogue, ea, (hipStream_t)stream);
   return ll_check_launch("ll_gemm_w8a8");
+}
+
+// Fused QKV projection with the V third written into the KV cache (see EpiArgs::v_out): ll_gemm_bf16 / ll_gemm_w8a8 with
+// LL_EPI_BIAS, N = 3 C, plus the cache destination.  The q and k thirds land in `out` [M, ldo] as usual (they still need the
+// full-row RMSNorm + RoPE of ll_qk_norm_rope_kv_store, called with cache_v = NULL afterwards); the v third of `out` is left
+// unwritten.  M = B * L tokens.
+static int check_v_insert(const char* fn, int M, int N, int B, int L, int S, int write_start, int roped_offset, int write_len,
+                          const void* cache_v) {
+  LL_REQUIRE(cache_v != nullptr, "%s: cache_v is required", fn);
+  LL_REQUIRE(N % 3 == 0 && (N / 3) % 8 == 0, "%s: N=%d must be 3 C with C a multiple of 8", fn, N);
+  LL_REQUIRE(B > 0 && L > 0 && M == B * L, "%s: M=%d is not B=%d x L=%d", fn, M, B, L);
+  LL_REQUIRE(write_len >= 0 && roped_offset >= 0 && (write_len == 0 || roped_offset + write_len <= L), "%s: write window outside the new tokens", fn);
+  LL_REQUIRE(write_len == 0 || (write_start >= 0 && write_start + write_len <= S), "%s: write [%d,+%d) outside cache of %d slots", fn, write_start, write_len, S);
+  return LL_OK;
+}
+
+extern "C" int ll_gemm_bf16_qkv(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
+                                int ldo, ll_bf16* cache_v, int B, int L, int S, int write_start, int roped_offset, int write_len,
+                                ll_stream stream) {
+  LL_REQUIRE(K > 0 && K % 64 == 0, "ll_gemm_bf16_qkv: K=%d must be a positive multiple of 64", K);
+  LL_REQUIRE(ldx >= K && ldx % 8 == 0, "ll_gemm_bf16_qkv: ldx=%d must be >= K and a multiple of 8", ldx);
+  int rc = check_epilogue("ll_gemm_bf16_qkv", M, N, ldo, LL_EPI_BIAS, bias, nullptr, nullptr, nullptr, 0, 0, 0, 0);
+  if (rc) return rc;
+  rc = check_v_insert("ll_gemm_bf16_qkv", M, N, B, L, S, write_start, roped_offset, write_len, cache_v);
+  if (rc) return rc;
+  if (M == 0) return LL_OK;
+  EpiArgs ea{(const bf16*)bias, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  ea.v_out = (bf16*)cache_v; ea.v_col0 = 2 * (N / 3); ea.v_C = N / 3; ea.v_L = L; ea.v_S = S;
+  ea.v_write_start = write_start; ea.v_roped_offset = roped_offset; ea.v_write_len = write_len;
+  launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, LL_EPI_BIAS, ea, (hipStream_t)stream);
+  return ll_check_launch("ll_gemm_bf16_qkv");
+}
+
+extern "C" int ll_gemm_w8a8_qkv(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias,
+                                ll_bf16* out, int M, int N, int K, int ldo, ll_bf16* cache_v, int B, int L, int S, int write_start,
+                                int roped_offset, int write_len, ll_stream stream) {
+  LL_REQUIRE(K > 0 && K % 128 == 0, "ll_gemm_w8a8_qkv: K=%d must be a positive multiple of 128", K);
+  LL_REQUIRE(sx && sw, "ll_gemm_w8a8_qkv: activation and weight scales are required");
+  int rc = check_epilogue("ll_gemm_w8a8_qkv", M, N, ldo, LL_EPI_BIAS, bias, nullptr, nullptr, nullptr, 0, 0, 0, 0);
+  if (rc) return rc;
+  rc = check_v_insert("ll_gemm_w8a8_qkv", M, N, B, L, S, write_start, roped_offset, write_len, cache_v);
+  if (rc) return rc;
+  if (M == 0) return LL_OK;
+  EpiArgs ea{(const bf16*)bias, nullptr, nullptr, nullptr, sx, sw, 0, 0, 0, 0, 0};
+  ea.v_out = (bf16*)cache_v; ea.v_col0 = 2 * (N / 3); ea.v_C = N / 3; ea.v_L = L; ea.v_S = S;
+  ea.v_write_start = write_start; ea.v_roped_offset = roped_offset; ea.v_write_len = write_len;
+  launch_gemm<true>(xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, LL_EPI_BIAS, ea, (hipStream_t)stream);
+  return ll_check_launch("ll_gemm_w8a8_qkv");
 }
 
 extern "C" int ll_quantize_rows(const ll_bf16* x, int8_t* q, float* scale, int rows, int K, int ldx, ll_stream stream) {

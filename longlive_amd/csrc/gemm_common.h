@@ -14,7 +14,20 @@ struct EpiArgs {
   const float* sx;                  // int8: per-row activation scale [M]
   const float* sw;                  // int8: per-output-channel weight scale [N]
   int nmod, gate_idx, rows_per_batch, frame_len, F;
+  // Fused QKV projection: output columns >= v_col0 (the V third) go straight into the KV cache instead of the output buffer,
+  // token t of batch b to cache row v_write_start + (t - v_roped_offset) when that index is in [0, v_write_len)
+  // (wan/modules/causal_model.py:264-269,302-311: `temp_v[:, write_start:local_end] = v[:, roped_offset:roped_offset + write_len]`).
+  bf16* v_out = nullptr;            // cache_v [B, v_S, C] or null
+  int v_col0 = 0, v_C = 0, v_L = 1, v_S = 0, v_write_start = 0, v_roped_offset = 0, v_write_len = 0;   // v_C = cache row width
 };
+
+// destination of output element block (row m, first column n) under the V redirect; nullptr = not stored
+__device__ __forceinline__ bf16* epi_dest(const EpiArgs& ea, bf16* __restrict__ Y, int ldo, int m, int n) {
+  if (ea.v_out == nullptr || n < ea.v_col0) return Y + (size_t)m * ldo + n;
+  int bb = m / ea.v_L, wi = m - bb * ea.v_L - ea.v_roped_offset;
+  if (wi < 0 || wi >= ea.v_write_len) return nullptr;
+  return ea.v_out + ((size_t)bb * ea.v_S + ea.v_write_start + wi) * (size_t)ea.v_C + (n - ea.v_col0);
+}
 
 template <bool I8>
 struct Ty;
@@ -132,7 +145,10 @@ __device__ __forceinline__ void gemm_epilogue(typename Ty<I8>::acc (&acc)[NTL][M
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = (bf16)((float)rv[bi][a][j] + v[j]);
         }
-        if (m < M && n < N) *reinterpret_cast<bf16x4*>(Y + (size_t)m * ldo + n) = o;
+        if (m < M && n < N) {
+          bf16* dst = epi_dest(ea, Y, ldo, m, n);
+          if (dst) *reinterpret_cast<bf16x4*>(dst) = o;
+        }
       }
     }
   }
@@ -222,7 +238,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(typename Ty<I8>::acc (&acc)[NT
       } else {
         o = v;
       }
-      if (ok[i]) *reinterpret_cast<bf16x8*>(Y + (size_t)(mw + row[i]) * ldo + nw + col[i]) = o;
+      if (ok[i]) {
+        bf16* dst = epi_dest(ea, Y, ldo, mw + row[i], nw + col[i]);
+        if (dst) *reinterpret_cast<bf16x8*>(dst) = o;
+      }
     }
   }
 }

@@ -123,6 +123,8 @@ class CausalWanModelHIP(nn.Module):
         # None: bf16 linears (the reference's precision).  "int8": W8A8 for the six per-token linears of every block
         # (BASELINE config 5; per-token activation scales, per-output-channel weight scales, int32 accumulation).
         self.quant: Optional[str] = None
+        self.use_modulation_table = True      # modulation + e0 once per (layer, frame) instead of once per token row (A/B switch)
+        self.fuse_v_insert = True             # the QKV projection's epilogue writes V into the KV cache (A/B switch)
         self._packed = None
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -294,16 +296,26 @@ class CausalWanModelHIP(nn.Module):
         sa, ca = blk.self_attn, blk.cross_attn
         # --- self attention (causal_model.py:444-456) ---
         q8 = self.quant == "int8"
-        h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 0, 1, F, c.eps)
-        qkv = self._lin(h1, pk, "qkv", pk["wqkv"], pk["bqkv"])
         G, E = _kv_state(kvc)
         S = kvc["k"].shape[1]
         plan = plan_update(current_start, L, G, E, S, self.sink_size * fs, self.local_attn_size,
                            sa.max_attention_size, sink_recache_after_switch)
-        if plan.roll is not None:
+        if plan.roll is not None:          # before the projection: its epilogue writes V into the rolled window
             ops.kv_roll(kvc["k"], kvc["v"], *plan.roll)
+        h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 0, 1, F, c.eps)
+        if self.fuse_v_insert:             # V third of the projection goes straight into its cache slots (GEMM epilogue)
+            if q8:
+                qkv = ops.gemm_qkv_v_insert(None, (pk["q_qkv"], pk["s_qkv"]), pk["bqkv"], kvc["v"], plan.write_start,
+                                            plan.roped_offset, plan.write_len, xq=h1)
+            else:
+                qkv = ops.gemm_qkv_v_insert(h1, pk["wqkv"], pk["bqkv"], kvc["v"], plan.write_start, plan.roped_offset,
+                                            plan.write_len)
+            v_dst = None
+        else:
+            qkv = self._lin(h1, pk, "qkv", pk["wqkv"], pk["bqkv"])
+            v_dst = kvc["v"]
         ops.qk_norm_rope_kv_store(qkv, sa.norm_q.weight, sa.norm_k.weight, rope_f, rope_hw, q_buf.view(B, L, C),
-                                  kvc["k"], kvc["v"], D, fs, current_start // fs, plan.write_start,
+                                  kvc["k"], v_dst, D, fs, current_start // fs, plan.write_start,
                                   plan.roped_offset, plan.write_len, c.eps)
         if kv_insert_only:
             return plan
@@ -360,11 +372,12 @@ class CausalWanModelHIP(nn.Module):
         plans: List[KVPlan] = []
         last = len(self.blocks) - 1
         P = self._pack()       # validated against the live parameters once per forward
-        etab = ops.modulation_table(e0, self._mods)      # [NL, B, F, 6, C] = modulation + e0 for every layer, one launch
+        premod = self.use_modulation_table
+        etab = ops.modulation_table(e0, self._mods) if premod else None   # [NL, B, F, 6, C] = modulation + e0, one launch
         for i in range(len(self.blocks)):
-            plans.append(self.block_forward(i, xs, etab[i], ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp), current_start,
-                                            sink_recache_after_switch, q_buf, kv_insert_only=kv_only and i == last,
-                                            pk=P[i], premod=True))
+            plans.append(self.block_forward(i, xs, etab[i] if premod else e0, ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp),
+                                            current_start, sink_recache_after_switch, q_buf,
+                                            kv_insert_only=kv_only and i == last, pk=P[i], premod=premod))
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)

@@ -185,14 +185,17 @@ def rmsnorm(x, w, eps: float, out=None, C: Optional[int] = None):
 
 def qk_norm_rope_kv_store(qkv, wq, wk, rope_f, rope_hw, q_out, cache_k, cache_v, head_dim: int, frame_len: int,
                           start_frame: int, write_start: int, roped_offset: int, write_len: int, eps: float):
-    """qkv [B,L,3C] -> q_out [B,L,C]; cache_k/v [B,S,H,D] rows [write_start, +write_len) updated in place."""
-    _chk(qkv, "qkv"); _chk(wq, "wq"); _chk(wk, "wk"); _chk(q_out, "q_out"); _chk(cache_k, "cache_k"); _chk(cache_v, "cache_v")
+    """qkv [B,L,3C] -> q_out [B,L,C]; cache_k/v [B,S,H,D] rows [write_start, +write_len) updated in place.  cache_v=None: V
+    was inserted by gemm_qkv_v_insert and the v third of qkv is not read."""
+    _chk(qkv, "qkv"); _chk(wq, "wq"); _chk(wk, "wk"); _chk(q_out, "q_out"); _chk(cache_k, "cache_k")
+    if cache_v is not None:
+        _chk(cache_v, "cache_v")
     _chk(rope_f, "rope_f", torch.float32); _chk(rope_hw, "rope_hw", torch.float32)
     B, L, C3 = qkv.shape
     Cc = C3 // 3
     assert C3 == 3 * Cc and q_out.shape == (B, L, Cc)
     S = cache_k.shape[1]
-    assert cache_k.shape[0] == B and cache_k.numel() == B * S * Cc and cache_v.shape == cache_k.shape
+    assert cache_k.shape[0] == B and cache_k.numel() == B * S * Cc and (cache_v is None or cache_v.shape == cache_k.shape)
     half = head_dim // 2
     nf = half - 2 * (half // 3)
     assert rope_f.shape == (1024, nf, 2), rope_f.shape
@@ -201,10 +204,11 @@ def qk_norm_rope_kv_store(qkv, wq, wk, rope_f, rope_hw, q_out, cache_k, cache_v,
     t0 = _t0("qk_norm_rope_kv_store")
     _lib.check(lib.ll_qk_norm_rope_kv_store(qkv.data_ptr(), wq.data_ptr(), wk.data_ptr(), rope_f.data_ptr(),
                                             rope_hw.data_ptr(), q_out.data_ptr(), cache_k.data_ptr(),
-                                            cache_v.data_ptr(), B, L, Cc, head_dim, frame_len, start_frame, S,
+                                            _ptr(cache_v), B, L, Cc, head_dim, frame_len, start_frame, S,
                                             write_start, roped_offset, write_len, eps, _stream()),
                "ll_qk_norm_rope_kv_store")
-    _t1("qk_norm_rope_kv_store", t0, 2.0 * (qkv.numel() + B * L * Cc + 2 * B * write_len * Cc))   # q,k,v in; q out; k,v -> cache
+    nv = 1 if cache_v is not None else 0
+    _t1("qk_norm_rope_kv_store", t0, 2.0 * ((2 + nv) * B * L * Cc + B * L * Cc + (1 + nv) * B * write_len * Cc))   # q,k(,v) in; q out; k(,v) -> cache
     return q_out
 
 
@@ -248,6 +252,45 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
                                 _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
                "ll_gemm_bf16")
     _t1(tag, t0, 2.0 * M * N * K)
+    return out
+
+
+def gemm_qkv_v_insert(x, w, bias, cache_v, write_start: int, roped_offset: int, write_len: int, xq=None, tag: str = "gemm_qkv"):
+    """The fused q|k|v projection x [B,L,K] @ w [3C,K]^T + bias with the V third inserted into cache_v [B,S,H,D] by the GEMM
+    epilogue (token t -> slot write_start + t - roped_offset for 0 <= t - roped_offset < write_len).  Returns the [B,L,3C]
+    buffer whose q and k thirds are valid (the v third is unwritten).  xq = (int8 [B,L,K], scale [B*L]) with int8 w = (wq, sw):
+    the W8A8 form."""
+    _chk(bias, "bias"); _chk(cache_v, "cache_v")
+    int8 = xq is not None
+    if int8:
+        xi, sx = xq
+        wq, sw = w
+        _chk(xi, "xq", torch.int8); _chk(sx, "sx", torch.float32); _chk(wq, "wq", torch.int8); _chk(sw, "sw", torch.float32)
+        B, L, K = xi.shape
+        N = wq.shape[0]
+        assert wq.shape == (N, K) and sx.numel() == B * L and sw.numel() == N
+        dev = xi.device
+    else:
+        _chk(x, "x"); _chk(w, "w")
+        B, L, K = x.shape
+        N = w.shape[0]
+        assert w.shape == (N, K)
+        dev = x.device
+    assert bias.numel() == N and N % 3 == 0
+    S = cache_v.shape[1]
+    assert cache_v.shape[0] == B and cache_v.numel() == B * S * (N // 3), (cache_v.shape, B, S, N)
+    out = torch.empty(B, L, N, dtype=bf16, device=dev)
+    lib = _lib.load()
+    t0 = _t0(tag)
+    if int8:
+        _lib.check(lib.ll_gemm_w8a8_qkv(xi.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                        B * L, N, K, N, cache_v.data_ptr(), B, L, S, write_start, roped_offset, write_len, _stream()),
+                   "ll_gemm_w8a8_qkv")
+    else:
+        _lib.check(lib.ll_gemm_bf16_qkv(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), B * L, N, K, K, N,
+                                        cache_v.data_ptr(), B, L, S, write_start, roped_offset, write_len, _stream()),
+                   "ll_gemm_bf16_qkv")
+    _t1(tag, t0, 2.0 * B * L * N * K)
     return out
 
 

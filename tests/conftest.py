@@ -23,3 +23,16 @@ def golden_dir():
 def load_golden(name):
     import torch
     return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _tuning_override():
+    """LL_TUNING_TEST=key=value,... applies ll_set_tuning before the GPU tests: the parity suite then checks that kernel
+    variant (used when A/B-ing variants on the GPU box)."""
+    spec = os.environ.get("LL_TUNING_TEST", "")
+    if spec:
+        from longlive_amd import _lib
+        for kv in filter(None, spec.split(",")):
+            k, v = kv.split("=")
+            _lib.check(_lib.load().ll_set_tuning(k.encode(), int(v)), "ll_set_tuning")
+    yield

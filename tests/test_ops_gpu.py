@@ -351,3 +351,49 @@ def test_modulation_table_paths_are_bit_identical(ops):
     a = ops.gemm(h, w, bias, ops.EPI_BIAS_GATE_RES, res=res, e=e, mod=mods[1], gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
     b = ops.gemm(h, w, bias, ops.EPI_BIAS_GATE_RES, res=res, e=tab[1], mod=None, gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,F,hp,wp,H,K,ws,ro,wl", [
+    (1, 3, 4, 6, 2, 256, 7, 0, 72),        # all new tokens inserted
+    (2, 2, 4, 6, 2, 256, 24, 9, 30),       # batch 2, sink-protected head (roped_offset) and a short window
+    (1, 1, 3, 5, 12, 1536, 45, 30, 0),     # nothing inserted (recompute inside the sink)
+    (1, 3, 30, 52, 12, 1536, 14040, 0, 4680),   # the steady-state launch: 4680 x 4608 x 1536 (256x192 tiles), last 3 frames of the window
+])
+def test_qkv_projection_with_v_insert_is_bit_identical(ops, B, F, hp, wp, H, K, ws, ro, wl):
+    """ll_gemm_bf16_qkv (V third written into the cache by the GEMM epilogue) + ll_qk_norm_rope_kv_store(cache_v=NULL) against
+    the unfused pair: q, the K cache and the V cache must not differ by a bit, untouched slots stay untouched.  Also W8A8."""
+    D = 128
+    C = H * D
+    fs, L = hp * wp, F * hp * wp
+    S = ws + wl + 11
+    x = hn("vx", (B, L, K)).to(DEV)
+    w, b = hn("vw", (3 * C, K), 1 / math.sqrt(K)).to(DEV), hn("vb", (3 * C,), 0.1).to(DEV)
+    wq, wk = hn("wq", (C,), 0.1, 1.0).to(DEV), hn("wk", (C,), 0.1, 1.0).to(DEV)
+    from longlive_amd.model import CausalWanModelHIP
+    m = CausalWanModelHIP(synth.toy_config(num_layers=1), device=DEV)
+    rope_f, rope_hw = m._rope_tables(hp, wp, DEV)
+    ck0, cv0 = hn("ck", (B, S, H, D)).to(DEV), hn("cv", (B, S, H, D)).to(DEV)
+
+    def run(fused, int8):
+        ck, cv = ck0.clone(), cv0.clone()
+        q = torch.empty(B, L, C, dtype=bf, device=DEV)
+        if int8:
+            xq, sx = ops.quantize_rows(x)
+            wq8, sw = ops.quantize_rows(w)
+        if fused:
+            qkv = (ops.gemm_qkv_v_insert(None, (wq8, sw), b, cv, ws, ro, wl, xq=(xq, sx)) if int8
+                   else ops.gemm_qkv_v_insert(x, w, b, cv, ws, ro, wl))
+            ops.qk_norm_rope_kv_store(qkv, wq, wk, rope_f, rope_hw, q, ck, None, D, fs, 3, ws, ro, wl, 1e-6)
+        else:
+            qkv = ops.gemm_w8a8(xq, sx, wq8, sw, b) if int8 else ops.gemm(x, w, b)
+            ops.qk_norm_rope_kv_store(qkv, wq, wk, rope_f, rope_hw, q, ck, cv, D, fs, 3, ws, ro, wl, 1e-6)
+        return q, ck, cv
+
+    for int8 in (False, True):
+        if int8 and K % 128:
+            continue
+        a, bq = run(False, int8), run(True, int8)
+        for u, v_, nm in zip(a, bq, ("q", "cache k", "cache v")):
+            assert torch.equal(u, v_), f"{nm} differs (int8={int8})"
+        mask = torch.ones(S, dtype=torch.bool); mask[ws:ws + wl] = False
+        assert torch.equal(bq[2][:, mask], cv0[:, mask])

@@ -1,0 +1,30 @@
+cat > /tmp/kb.py <<'PY'
+import ctypes as C, sys, os, torch, time
+sys.path.insert(0, os.getcwd())
+from longlive_amd import _lib, ops
+lib=_lib.load()
+def run(tag, stag):
+    _lib.check(lib.ll_set_tuning(b"gemm_stagger", stag), "t")
+    out=[]
+    for name,(M,N,K,epi) in {"o":(4680,1536,1536,2),"f2":(4680,1536,8960,2),"cq":(4680,1536,1536,0)}.items():
+        x=torch.randn(M,K,device="cuda").bfloat16(); w=(torch.randn(N,K,device="cuda")/K**0.5).bfloat16(); b=torch.zeros(N,device="cuda").bfloat16()
+        res=torch.randn(M,N,device="cuda").bfloat16(); e=torch.randn(1,3,6,N,device="cuda").bfloat16(); mod=torch.randn(6,N,device="cuda").bfloat16()
+        kw=dict(res=res,e=e,mod=mod,gate_idx=2,rows_per_batch=M,frame_len=M//3) if epi==2 else {}
+        ref=(x.float()@w.float().t())
+        got=ops.gemm(x,w,b,0)
+        err=(got.float()-ref).abs().max().item()
+        for _ in range(3): ops.gemm(x,w,b,epi,**kw)
+        torch.cuda.synchronize(); t0=time.perf_counter()
+        for _ in range(30): ops.gemm(x,w,b,epi,**kw)
+        torch.cuda.synchronize(); out.append(f"{name} {(time.perf_counter()-t0)/30*1e6:.1f}us (err {err:.3f})")
+    print(tag, " ".join(out), flush=True)
+for rep in range(3):
+    run("base   ", 0)
+    run("stagger", 1)
+PY
+python /tmp/kb.py 2>&1 | grep -v amdgpu.ids
+for rep in 1 2; do for st in 1 0; do
+LL_TUNING=gemm_stagger=$st python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-extras > /tmp/b.json 2>/tmp/b.err || { tail -3 /tmp/b.err; exit 1; }
+python -c "
+import json; d=json.load(open('/tmp/b.json')); print('stagger=$st', round(d['value'],2), 'f/s', round(d['ms_per_step'],2))"
+done; done
