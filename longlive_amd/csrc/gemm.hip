@@ -234,10 +234,10 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict_
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // tile kt is in LDS for every wave; the other stage is no longer being read
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && !(lds_epi & 0x100)) stage(kt + 1, (kt + 1) & 1);      // (0x100 / 0x200: timing experiments, results invalid)
     const char* xs = smem + (kt & 1) * STAGE;
     const char* ws = xs + 256 * ROWB;
-    if (!live) continue;               // rows past M: stage and sync only (see v2)
+    if (!live || (lds_epi & 0x200)) continue;               // rows past M: stage and sync only (see v2)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -262,6 +262,111 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v5(const char* __restrict_
   }
   if (lds_epi) {
     __builtin_amdgcn_s_barrier();
+    gemm_epilogue_lds<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, lane,
+                                       smem + wave * (MT * 16 * EPI_ROW_BYTES(NT)), ea);
+  } else {
+    gemm_epilogue<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, fr, fg, ea);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ws ("wave-specialised"): the v2 / v5 tiles with the LDS-DMA staging moved OFF the compute waves.
+//
+// Why: timing the K-loop with parts switched off (profiles/r02_ab_gemm_epilogue.txt) shows staging alone at 0.42 (256x128) /
+// 0.81 us (256x224) per K-step and LDS reads + MFMAs alone at 0.69 / 1.05 us, but the two together at 0.91 / 1.46 us: they do
+// not overlap.  The CU's LDS-DMA path moves ~35-50 bytes per clock; the 48-60 one-KiB pieces of a K-step fill its queue, every
+// wave that issues one stalls IN ORDER behind it, and after a barrier all eight waves issue theirs at once -- the matrix pipe
+// idles for the length of the issue burst.  Here waves 0-7 only read fragments and issue MFMAs; NL extra waves (one or two,
+// co-resident on SIMD 0 / 1 as a third wave) issue every piece and absorb the back-pressure.  One workgroup barrier per
+// K-step as before: the loader passes it once its pieces of tile kt have landed (counted vmcnt), the compute waves once they
+// are done with tile kt-1, and the loader then restages the slot tile kt-1 occupied.
+//   STAGES = 3 for the 256x128 tile (144 KiB), 2 for 256x192 / 256x224 (the ring would not fit three).
+template <int EPI, bool I8, int WM, int WN, int MT, int NT, int STAGES, int NL>
+__global__ __launch_bounds__(512 + 64 * NL, 1) void gemm_kernel_ws(const char* __restrict__ X, const char* __restrict__ Wt,
+                                                                     bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
+                                                                     size_t wrow_bytes, int ldo, int ntm, int ntn, int gm,
+                                                                     int lds_epi, EpiArgs ea) {
+  static_assert(WM * WN == 8 && WM * MT * 16 == 256, "8 compute waves, 256 rows");
+  static_assert(NL == 1 || NL == 2, "one or two loader waves");
+  constexpr int BNv = WN * NT * 16, STAGE = (256 + BNv) * ROWB, NB = BNv / 8;   // NB = W pieces (8 rows x 128 B) per K-step
+  constexpr int PX = 32 / NL, PW = (NB + NL - 1) / NL;                          // pieces per loader wave
+  static_assert((PX + PW) * (STAGES - 2) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Ty<I8>::frag frag_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lid = xcd_remap(blockIdx.x, ntm * ntn), mt_, nt_;
+  tile_of(lid, ntm, ntn, gm, mt_, nt_);
+  const int m0 = mt_ * 256, n0 = nt_ * BNv;
+
+  if (wave >= 8) {
+    // ---- loader wave(s): all LDS-DMA of the workgroup -------------------------------------------------------------------
+    const int li = wave - 8;
+    auto stage = [&](int kt, int slot) {
+      char* base = smem + slot * STAGE;
+      stage_rows(X, xrow_bytes, m0, M, kt * ROWB, base, li * PX, PX, lane);
+      int w0 = li * PW, wn_ = NB - w0 < PW ? NB - w0 : PW;
+#pragma unroll
+      for (int i = 0; i < PW; ++i)
+        if (i < wn_) stage_rows(Wt, wrow_bytes, n0, N, kt * ROWB, base + 256 * ROWB, w0 + i, 1, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+      if (t < nk) stage(t, t);
+    int slot_new = STAGES - 1;                       // slot the next staged tile goes to
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed when at most the younger tiles' pieces are outstanding (STAGES - 2 tiles of PX + PW pieces; the
+      // loader of a 2-stage ring has nothing younger in flight)
+      if (STAGES == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PX + PW) * (STAGES - 2)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // tile kt visible to the compute waves; they are done with tile kt - 1
+      if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, slot_new);
+      slot_new = slot_new == STAGES - 1 ? 0 : slot_new + 1;
+    }
+    if (lds_epi) __builtin_amdgcn_s_barrier();       // the compute waves' "ring is free" barrier before the staged epilogue
+    return;
+  }
+
+  // ---- compute waves ------------------------------------------------------------------------------------------------------
+  const int wm = wave / WN, wn = wave % WN;
+  typename Ty<I8>::acc acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = acc_zero<I8>();
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool live = m0 + wm * MT * 16 < M;      // wave-uniform
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    const char* xs = smem + slot * STAGE;
+    const char* ws = xs + 256 * ROWB;
+    slot = slot == STAGES - 1 ? 0 : slot + 1;
+    if (!live) continue;               // rows past M: sync only
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t wf[NT], xf[MT];
+      int ch = ks * 4 + fg;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        int rw = wn * NT * 16 + t * 16 + fr;
+        wf[t] = *reinterpret_cast<const frag_t*>(ws + rw * ROWB + ((ch ^ (rw & 7)) << 4));
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        int rx = wm * MT * 16 + t * 16 + fr;
+        xf[t] = *reinterpret_cast<const frag_t*>(xs + rx * ROWB + ((ch ^ (rx & 7)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int a = 0; a < NT; ++a) acc[a][b] = Ty<I8>::mma(wf[a], xf[b], acc[a][b]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  if (lds_epi) {
+    __builtin_amdgcn_s_barrier();      // every wave has read its last K-step's fragments: the ring is free
     gemm_epilogue_lds<EPI, I8, NT, MT>(acc, Y, M, N, ldo, m0 + wm * MT * 16, n0 + wn * NT * 16, lane,
                                        smem + wave * (MT * 16 * EPI_ROW_BYTES(NT)), ea);
   } else {
@@ -382,6 +487,8 @@ static int g_gemm_variant_wide = 0;  // like gemm_variant, but only for N >= 409
 // 1: epilogue staged through LDS (whole-line residual loads / stores) in the v2 / v5 tilings, except the GELU epilogue, whose
 // register form measured 1.6 % faster (FFN1 127.2 vs 129.3 us; everything else 1.5-11 % faster staged); 2: all; 0: none
 static int g_gemm_lds_epi = 1;
+static int g_gemm_ws_mask = 15;     // which launches gemm_ws applies to: 1 = 256x128 with K >= 4096 (FFN2), 2 = 256x128 otherwise, 4 = 256x192, 8 = 256x224
+static int g_gemm_ws = 0;            // wave-specialised staging (gemm_kernel_ws): 0 off, 1 / 2 loader waves, for variants 2, 5, 6
 static int g_gemm_stagger = 0;       // 1: 256x128 tiling with waves 4-7 half a K-step behind (gemm_kernel_v2<.., true>)
 static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
@@ -393,6 +500,8 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant_wide")) { g_gemm_variant_wide = value; return LL_OK; }
   if (!strcmp(key, "gemm_lds_epi")) { g_gemm_lds_epi = value; return LL_OK; }
   if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return LL_OK; }
+  if (!strcmp(key, "gemm_ws")) { g_gemm_ws = value; return LL_OK; }
+  if (!strcmp(key, "gemm_ws_mask")) { g_gemm_ws_mask = value; return LL_OK; }
   if (!strcmp(key, "attn_variant")) { ll_set_attn_variant_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
@@ -534,8 +643,27 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
   const int lds_epi = ((g_gemm_lds_epi & 3) == 2 || ((g_gemm_lds_epi & 3) == 1 && epilogue != LL_EPI_BIAS_GELU) ? 1 : 0) |
                       (g_gemm_lds_epi & 0x300);   // 0x100 / 0x200: timing experiments (no in-loop staging / no compute), results invalid
   size_t lds = v3 ? 2 * V3_STAGE : (v5 || v6) ? 2 * (size_t)(256 + bn) * ROWB : 3 * V2_STAGE;
+#define LAUNCH_WS(E, WM_, WN_, MT_, NT_, ST_, NL_)                                                                     \
+  do {                                                                                                                 \
+    static bool aws = false;                                                                                           \
+    if (!aws) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel_ws<E, I8, WM_, WN_, MT_, NT_, ST_, NL_>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
+      aws = true;                                                                                                      \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gemm_kernel_ws<E, I8, WM_, WN_, MT_, NT_, ST_, NL_>), grid, dim3(512 + 64 * NL_), lds, s,      \
+                       (const char*)x, (const char*)w, out, M, N, nk, xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea); \
+  } while (0)
 #define LAUNCH(E)                                                                                                      \
   do {                                                                                                                 \
+    const int wsb = v5 ? 4 : v6 ? 8 : (variant == 2 ? (nk >= 64 ? 1 : 2) : 0);                                         \
+    const int wsn = (g_gemm_ws_mask & wsb) ? g_gemm_ws : 0;                                                            \
+    if (wsn == 1 && v5) { LAUNCH_WS(E, 2, 4, 8, 3, 2, 1); break; }                                                     \
+    if (wsn == 2 && v5) { LAUNCH_WS(E, 2, 4, 8, 3, 2, 2); break; }                                                     \
+    if (wsn == 1 && v6) { LAUNCH_WS(E, 4, 2, 4, 7, 2, 1); break; }                                                     \
+    if (wsn == 2 && v6) { LAUNCH_WS(E, 4, 2, 4, 7, 2, 2); break; }                                                     \
+    if (wsn == 1 && variant == 2) { LAUNCH_WS(E, 4, 2, 4, 4, 3, 1); break; }                                           \
+    if (wsn == 2 && variant == 2) { LAUNCH_WS(E, 4, 2, 4, 4, 3, 2); break; }                                           \
     if (v5 || v6) {                                                                                                    \
       static bool a5 = false;                                                                                          \
       if (!a5) {                                                                                                       \

@@ -1,0 +1,31 @@
+mkdir -p gpurun_out/r02m
+for wsv in 1 2; do
+LL_TUNING_TEST=gemm_ws=$wsv timeout -k 10 300 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "gemm or int8 or epilogue or modulation or v_insert" > gpurun_out/r02m/tests_ws$wsv.log 2>&1; rc=$?; echo "pytest ws=$wsv rc=$rc"; tail -3 gpurun_out/r02m/tests_ws$wsv.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+done
+cat > /tmp/kb.py <<'PY'
+import sys, os, torch, time
+sys.path.insert(0, os.getcwd())
+from longlive_amd import _lib, ops
+lib=_lib.load()
+def run(tag, wsv):
+    _lib.check(lib.ll_set_tuning(b"gemm_ws", wsv), "t")
+    out=[]
+    for name,(M,N,K,epi) in {"qkv":(4680,4608,1536,0),"f1":(4680,8960,1536,1),"o":(4680,1536,1536,2),"f2":(4680,1536,8960,2),"cq":(4680,1536,1536,0)}.items():
+        x=torch.randn(M,K,device="cuda").bfloat16(); w=(torch.randn(N,K,device="cuda")/K**0.5).bfloat16(); b=torch.zeros(N,device="cuda").bfloat16()
+        res=torch.randn(M,N,device="cuda").bfloat16(); e=torch.randn(1,3,6,N,device="cuda").bfloat16(); mod=torch.randn(6,N,device="cuda").bfloat16()
+        kw=dict(res=res,e=e,mod=mod,gate_idx=2,rows_per_batch=M,frame_len=M//3) if epi==2 else {}
+        for _ in range(3): ops.gemm(x,w,b,epi,**kw)
+        torch.cuda.synchronize(); t0=time.perf_counter()
+        for _ in range(30): ops.gemm(x,w,b,epi,**kw)
+        torch.cuda.synchronize(); out.append(f"{name} {(time.perf_counter()-t0)/30*1e6:.1f}us")
+    print(tag, " ".join(out), flush=True)
+for rep in range(2):
+    run("ws=0", 0); run("ws=1", 1); run("ws=2", 2)
+PY
+timeout -k 10 200 python /tmp/kb.py 2>&1 | grep -v amdgpu.ids
+for rep in 1 2; do for wsv in 0 1 2; do
+LL_TUNING=gemm_ws=$wsv timeout -k 10 200 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-extras > /tmp/b.json 2>/tmp/b.err || { tail -3 /tmp/b.err; exit 1; }
+python -c "
+import json; d=json.load(open('/tmp/b.json')); print('gemm_ws=$wsv', round(d['value'],2), 'f/s', round(d['ms_per_step'],2))"
+done; done

@@ -58,6 +58,19 @@ int main(int argc, char** argv) {
   std::vector<double> idle;
   for (auto& f : files) idle.push_back(read_w(f));
 
+  // LL_TUNING=key=value,...: the same kernel A/B switches bench.py accepts
+  if (const char* tun = getenv("LL_TUNING")) {
+    std::string t(tun);
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t c = t.find(',', pos);
+      std::string kv = t.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+      size_t eq = kv.find('=');
+      if (eq != std::string::npos) LL(ll_set_tuning(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)));
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+  }
   int M = 4680, N = 0, K = 0, epi = 0;
   bool attn = !strcmp(what, "attn") || !strcmp(what, "cross");
   if (!strcmp(what, "qkv")) { N = 4608; K = 1536; }
@@ -81,7 +94,7 @@ int main(int argc, char** argv) {
     fn = [=]() { LL(ll_flash_attn(q, k, v, o, 1, M, H, H * 128, H * 128, H * 128, (long long)Lk * H * 128, 0, Lk, 0, 0, scale, ws, ws_bytes, s)); };
     flops = 4.0 * M * Lk * H * 128;
   } else {
-    LL(ll_set_tuning("gemm_variant", variant));
+    if (variant > 0) LL(ll_set_tuning("gemm_variant", variant));
     auto* x = (ll_bf16*)dalloc((size_t)M * K * 2, 1.0f);
     auto* w = (ll_bf16*)dalloc((size_t)N * K * 2, 1.0f / sqrtf((float)K));
     auto* b = (ll_bf16*)dalloc((size_t)N * 2, 0.1f);
