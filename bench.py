@@ -497,14 +497,15 @@ def launch_replicas(args, argv):
     """Starts N children before this process has touched the GPU (no torch.cuda call above this line in the parent), one
     device each, and acts as their rendezvous.  No retry: any child failure ends the run with a non-zero exit."""
     n = args.gpus
+    ndev = n
     if not args.stub_workload:
         ndev = torch.cuda.device_count()                       # counting devices does not initialise HIP on this image
-        if ndev < n:
+        if ndev < n and os.environ.get("LL_BENCH_SHARE_GPUS") != "1":     # (=1: rehearsal of the launcher on fewer GPUs)
             raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible")
     procs = []
     for r in range(n):
         env = dict(os.environ)
-        env.update(LL_BENCH_CHILD="1", LL_BENCH_RANK=str(r), LL_BENCH_WORLD=str(n), HIP_VISIBLE_DEVICES=str(r),
+        env.update(LL_BENCH_CHILD="1", LL_BENCH_RANK=str(r), LL_BENCH_WORLD=str(n), HIP_VISIBLE_DEVICES=str(r % max(1, ndev)),
                    HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.pop("ROCR_VISIBLE_DEVICES", None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.PIPE,

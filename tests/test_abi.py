@@ -57,6 +57,11 @@ def test_no_torch_types_in_the_abi():
     (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 0, 0, 0, 0.088, None, 0, None), "non-empty"),
     (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 64, 0, 0, 0.088, None, 4096, None), "workspace"),
     (lambda L: L.ll_linear_small(0, 0, 0, 0, 9, 64, 64, 0, 0, None), "M=9"),
+    (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 0, 1, 128, 64, 0, 0, 128, None), "cache_v"),
+    (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 1, 1, 100, 64, 0, 0, 10, None), "not B"),
+    (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 1, 1, 128, 64, 60, 0, 10, None), "outside cache"),
+    (lambda L: L.ll_gemm_bf16(0, 0, 1, 0, 128, 128, 128, 128, 128, 2, 0, 0, 0, 6, 2, 128, 64, None), "res and e"),
+    (lambda L: L.ll_modulation_table(0, 0, 0, 30, 3, 6, 1537, None), "bad shape"),
 ])
 def test_invalid_arguments_are_rejected_before_launch(call, needle):
     lib = _lib.load()

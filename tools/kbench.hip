@@ -214,11 +214,16 @@ static void bench_shipped(int iters) {
   struct G { const char* tag; int N, K, epi; } gs[] = {{"gemm_qkv", 3 * C, C, LL_EPI_BIAS}, {"gemm_o", C, C, LL_EPI_BIAS_GATE_RES},
       {"gemm_cq", C, C, LL_EPI_BIAS}, {"gemm_co", C, C, LL_EPI_BIAS_RES}, {"gemm_f1", F1, C, LL_EPI_BIAS_GELU},
       {"gemm_f2", C, F1, LL_EPI_BIAS_GATE_RES}};
+  Buf vcache((size_t)S * C, 1.0f);
   for (auto& g : gs) {
     Buf x((size_t)L * g.K, 1.0f), w((size_t)g.N * g.K, 1.0f / sqrtf((float)g.K)), bias(g.N, 0.1f), out((size_t)L * g.N, 0.f);
-    Buf res((size_t)L * g.N, 1.0f), e((size_t)3 * 6 * g.N, 0.5f), mod((size_t)6 * g.N, 0.1f);
+    Buf res((size_t)L * g.N, 1.0f), e((size_t)3 * 6 * g.N, 0.5f);
+    const bool qkv = !strcmp(g.tag, "gemm_qkv");
     double ms = time_ms(s, iters, [&]() {
-      LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, mod.d, 6, 2, L, FS, s));
+      if (qkv)      // as shipped: the V third goes straight into the KV cache
+        LL(ll_gemm_bf16_qkv(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, vcache.d, 1, L, S, S - L, 0, L, s));
+      else          // as shipped: `e` is a layer's slice of ll_modulation_table (mod = NULL)
+        LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, nullptr, 6, 2, L, FS, s));
     });
     LL(ll_gemm_plan(L, g.N, g.K, 0, plan, sizeof plan));
     double fl = 2.0 * L * g.N * g.K, by = 2.0 * ((double)L * g.K + (double)g.N * g.K + (double)L * g.N * (g.epi >= 2 ? 2 : 1));
@@ -246,7 +251,7 @@ static void bench_shipped(int iters) {
   // ---- row kernels (HBM-bound)
   {
     Buf x((size_t)L * C, 1.7f), out((size_t)L * C, 0.f), e((size_t)3 * 6 * C, 0.5f), mod((size_t)6 * C, 0.1f), w(C, 0.1f), b(C, 0.1f);
-    double ms = time_ms(s, iters, [&]() { LL(ll_ln_modulate(x.d, out.d, e.d, mod.d, 6, 0, 1, 1, L, C, 3, 1e-6f, s)); });
+    double ms = time_ms(s, iters, [&]() { LL(ll_ln_modulate(x.d, out.d, e.d, nullptr, 6, 0, 1, 1, L, C, 3, 1e-6f, s)); });
     printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "ln_mod", "ln_modulate_kernel", ms * 1e3, 4.0 * L * C / (ms * 1e-3) / 1e9);
     work_line("ln_modulate", "ln_modulate_kernel", 0, 4.0 * L * C, ms * 1e3, "hbm");
     ms = time_ms(s, iters, [&]() { LL(ll_layernorm_affine(x.d, w.d, b.d, out.d, L, C, 1e-6f, s)); });
@@ -265,10 +270,10 @@ static void bench_shipped(int iters) {
     CK(hipMalloc(&rf, hrf.size() * 4)); CK(hipMalloc(&rhw, hrhw.size() * 4));
     CK(hipMemcpy(rf, hrf.data(), hrf.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(rhw, hrhw.data(), hrhw.size() * 4, hipMemcpyHostToDevice));
     double ms = time_ms(s, iters, [&]() {
-      LL(ll_qk_norm_rope_kv_store(qkv.d, wq.d, wk.d, rf, rhw, qo.d, ck.d, cv.d, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
-    });
-    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "qk_rope_kv", "qk_norm_rope_kv_kernel", ms * 1e3, 12.0 * L * C / (ms * 1e-3) / 1e9);
-    work_line("qk_norm_rope_kv_store", "qk_norm_rope_kv_kernel", 0, 12.0 * L * C, ms * 1e3, "hbm");
+      LL(ll_qk_norm_rope_kv_store(qkv.d, wq.d, wk.d, rf, rhw, qo.d, ck.d, nullptr, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
+    });     // as shipped: cache_v = NULL (V was inserted by the projection): q, k in; q out; k -> cache
+    printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "qk_rope_kv", "qk_norm_rope_kv_kernel", ms * 1e3, 8.0 * L * C / (ms * 1e-3) / 1e9);
+    work_line("qk_norm_rope_kv_store", "qk_norm_rope_kv_kernel", 0, 8.0 * L * C, ms * 1e3, "hbm");
     ms = time_ms(s, iters, [&]() { LL(ll_kv_roll(ck.d, cv.d, 1, S, C, 3 * FS, 6 * FS, 6 * FS, s)); });
     printf("%-10s %-60s %8.1f us %7.1f GB/s\n", "kv_roll", "copy_rows_kernel (2 launches)", ms * 1e3, 8.0 * 6 * FS * C / (ms * 1e-3) / 1e9);
     work_line("kv_roll", "copy_rows_kernel", 0, 8.0 * 6 * FS * C, ms * 1e3, "hbm");
