@@ -392,6 +392,8 @@ def run_replica(args, rank, world, local_rank, sync):
     if os.environ.get("LL_FUSE_V") == "0":
         gen.model.fuse_v_insert = False
     pipe = CausalInferencePipeline(_pipe_args(), dev, generator=gen)
+    if os.environ.get("LL_OVERLAP") == "0":                            # A/B only: context pass on the main stream
+        pipe.overlap_context = False
     extra_blocks = 0 if (args.no_extras or rank != 0) else 1           # one more steady-state block for the kernels table
     nblocks = args.warmup + args.steps + extra_blocks
     T = 3 * nblocks
@@ -418,7 +420,7 @@ def run_replica(args, rank, world, local_rank, sync):
     elapsed = time.perf_counter() - t0
     ops.timer = None
     res = dict(frames=args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed=elapsed, roofline=None, kernels=None, extras=None,
-               cpu_baseline=None)
+               cpu_baseline=None, overlap_context=bool(pipe.overlap_context))
     if rank != 0:
         return res
     if ktimer is not None and "flash_attn_self" in ktimer.records:
@@ -439,9 +441,13 @@ def run_replica(args, rank, world, local_rank, sync):
                            + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,
                            "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_source": src, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
-                           "flop_per_launch": s["work_per_launch"], "share_of_step": s["total_ms"] / (1e3 * elapsed)}
+                           "flop_per_launch": s["work_per_launch"], "share_of_step": s["total_ms"] / (1e3 * elapsed),
+                           "note": ("1 of 5 attention launches per layer runs beside the next block's first forward on a second "
+                                    "stream (context pass overlap), which lengthens those launches; the `kernels` table is taken "
+                                    "on one stream") if pipe.overlap_context else None}
     if extra_blocks:
         try:
+            pipe.overlap_context = False                               # one stream: per-kernel times without a co-running forward
             ops.timer = ops.KernelTimer()                              # every tagged launch of one more steady-state block
             torch.cuda.synchronize()
             t0 = time.perf_counter()

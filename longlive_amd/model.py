@@ -272,13 +272,16 @@ class CausalWanModelHIP(nn.Module):
     def block_forward(self, i: int, xs: torch.Tensor, e0: torch.Tensor, ctx: Optional[torch.Tensor], kvc: dict,
                       cac: dict, F: int, grid_hw: Tuple[int, int], current_start: int,
                       sink_recache_after_switch: bool = False, q_buf: Optional[torch.Tensor] = None,
-                      kv_insert_only: bool = False, pk: Optional[dict] = None, premod: bool = False) -> KVPlan:
+                      kv_insert_only: bool = False, pk: Optional[dict] = None, premod: bool = False,
+                      cache_done_event=None) -> KVPlan:
         """CausalWanAttentionBlock.forward (causal_model.py:413-477) for block `i`: updates the residual stream
         xs [B, L, C] IN PLACE (L = F * hp * wp tokens, grid_hw = (hp, wp) tokens per frame) and this layer's KV / cross
         caches, returns the layer's KV plan (the caller commits the end indices after all layers,
         causal_model.py:1061-1062).  e0 [B, F, 6, C]; ctx = embedded text [B, 512, C] (only read when the cross cache is
         not initialised).  kv_insert_only: stop after the K/V insert.  premod: `e0` is this layer's slice of
-        ops.modulation_table (modulation already added), as forward_frames passes it."""
+        ops.modulation_table (modulation already added), as forward_frames passes it.  cache_done_event: recorded on the
+        current stream right after this layer's LAST access to its KV cache (the self-attention launch, or the insert when
+        kv_insert_only) -- a forward on another stream may touch the layer's cache from then on."""
         c = self.cfg
         B, L, C = xs.shape
         Hh, D = c.num_heads, c.head_dim
@@ -318,8 +321,12 @@ class CausalWanModelHIP(nn.Module):
                                   kvc["k"], v_dst, D, fs, current_start // fs, plan.write_start,
                                   plan.roped_offset, plan.write_len, c.eps)
         if kv_insert_only:
+            if cache_done_event is not None:
+                cache_done_event.record(torch.cuda.current_stream())
             return plan
         att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
+        if cache_done_event is not None:
+            cache_done_event.record(torch.cuda.current_stream())
         self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
                   mod=mod, gate_idx=2, rows_per_batch=L, frame_len=fs)
         # --- cross attention (causal_model.py:460; model.py:159-194) ---
@@ -347,13 +354,17 @@ class CausalWanModelHIP(nn.Module):
     def forward_frames(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, kv_cache: List[dict],
                        crossattn_cache: List[dict], current_start: int = 0,
                        sink_recache_after_switch: bool = False, sigma: Optional[torch.Tensor] = None,
-                       kv_only: bool = False):
+                       kv_only: bool = False, layer_wait=None, layer_record=None):
         """x [B,F,Cin,H,W] (the wrapper's layout); t [B,F]; context [B,text_len,text_dim].
         Returns the head output [B, L, 4*Cout] (pre-unpatchify), or (flow, x0) in [B,F,C,H,W] when `sigma`
         (float32 [B*F]) is given.  kv_only: the caller discards the output and only wants the KV caches updated (the
         clean-context pass and the recache pass, causal_inference.py:192-200, interactive_causal_inference.py:34-106):
         everything after the last layer's K/V insert -- its attention, cross-attention, FFN and the head -- is skipped and
-        None is returned; the caches end up bit-identical."""
+        None is returned; the caches end up bit-identical.
+        layer_wait / layer_record: per-layer HIP events for running TWO forwards on two streams one layer apart (the pipelines
+        overlap a block's clean-context pass with the next block's first denoising forward): before touching layer i's caches
+        this forward waits for layer_wait[i]; right after layer i's last cache access (its self-attention launch) it records
+        layer_record[i] on its stream."""
         c = self.cfg
         B, F, Cin, H, W = x.shape
         hp, wp = H // 2, W // 2
@@ -374,10 +385,14 @@ class CausalWanModelHIP(nn.Module):
         P = self._pack()       # validated against the live parameters once per forward
         premod = self.use_modulation_table
         etab = ops.modulation_table(e0, self._mods) if premod else None   # [NL, B, F, 6, C] = modulation + e0, one launch
+        cur_stream = torch.cuda.current_stream() if (layer_wait is not None or layer_record is not None) else None
         for i in range(len(self.blocks)):
+            if layer_wait is not None:
+                cur_stream.wait_event(layer_wait[i])
             plans.append(self.block_forward(i, xs, etab[i] if premod else e0, ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp),
                                             current_start, sink_recache_after_switch, q_buf,
-                                            kv_insert_only=kv_only and i == last, pk=P[i], premod=premod))
+                                            kv_insert_only=kv_only and i == last, pk=P[i], premod=premod,
+                                            cache_done_event=layer_record[i] if layer_record is not None else None))
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)

@@ -52,6 +52,15 @@ class CausalInferencePipeline(nn.Module):
         self.randn_like = torch.randn_like      # re-noise source (causal_inference.py:175); tests inject a hash RNG
         self.last_profile = None
         self.verbose = False
+        # Two HIP streams: a block's clean-context pass (output discarded, only refreshes the KV cache) runs on `_aux` while the
+        # NEXT block's first denoising forward -- whose input is fresh noise -- runs on the main stream one layer behind it
+        # (per-layer events: layer i of the follower waits until the context pass has left layer i's cache).  Same kernels on
+        # the same data in the same per-cache order: bit-identical results (tests/test_model_gpu.py).  One stream's low-power
+        # phases (epilogues, row kernels, launch ramps) then overlap the other's dense kernels.
+        self.overlap_context = True
+        self._aux = None
+        self._ctx_events = None
+        self._ctx_pending = False
 
     # ------------------------------------------------------------------------------------------------------------
     def _encode(self, text_prompts):
@@ -74,8 +83,12 @@ class CausalInferencePipeline(nn.Module):
         denoised = None
         for index, tval in enumerate(self._step_values):
             timestep = self._timestep(tval, batch_size, nframes, dev)
+            kw = {}
+            if self._ctx_pending:        # the previous block's context pass is still running on the aux stream
+                kw["layer_wait"] = self._ctx_events
+                self._ctx_pending = False      # later forwards are ordered behind this one on the main stream
             _, denoised = self.generator(noisy_image_or_video=noisy_input, conditional_dict=cond, timestep=timestep,
-                                         kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=cs)
+                                         kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=cs, **kw)
             if index < len(self._step_values) - 1:
                 nxt = self._timestep(self._step_values[index + 1], batch_size * nframes, 1, dev).view(-1)
                 flat = denoised.flatten(0, 1)
@@ -91,11 +104,37 @@ class CausalInferencePipeline(nn.Module):
         """Re-run at t = context_noise so the cache holds clean-frame K/V (causal_inference.py:192-200)."""
         B, nf = denoised.shape[:2]
         ctx_t = self._timestep(float(getattr(self.args, "context_noise", 0)), B, nf, denoised.device)
+        if self._use_overlap(denoised):
+            main = torch.cuda.current_stream(denoised.device)
+            if self._aux is None:
+                self._aux = torch.cuda.Stream(device=denoised.device)
+                self._ctx_events = [torch.cuda.Event() for _ in range(self.num_transformer_blocks)]
+            self._aux.wait_stream(main)             # the denoised latents (and this block's K/V inserts) are ready
+            denoised.record_stream(self._aux)       # allocated on the main stream, read by the aux stream
+            ctx_t.record_stream(self._aux)
+            with torch.cuda.stream(self._aux):
+                self.generator(noisy_image_or_video=denoised, conditional_dict=cond, timestep=ctx_t, kv_cache=self.kv_cache1,
+                               crossattn_cache=self.crossattn_cache, current_start=start_frame * self.frame_seq_length,
+                               layer_record=self._ctx_events, **self._kv_only_kw())
+            self._ctx_pending = True
+            return
         self.generator(noisy_image_or_video=denoised, conditional_dict=cond, timestep=ctx_t, kv_cache=self.kv_cache1,
                        crossattn_cache=self.crossattn_cache, current_start=start_frame * self.frame_seq_length,
                        **self._kv_only_kw())
 
+    def _use_overlap(self, t: torch.Tensor) -> bool:
+        return (self.overlap_context and t.is_cuda and getattr(self.generator, "supports_layer_events", False)
+                and getattr(self.generator, "supports_kv_only", False))
+
+    def _join_context(self):
+        """Make the main stream wait for an outstanding context pass (before anything but the next block's first forward
+        touches the caches: a recache, the end of a run, a caller that reads the caches)."""
+        if self._aux is not None and self._ctx_pending:
+            torch.cuda.current_stream(self._aux.device).wait_stream(self._aux)
+        self._ctx_pending = False
+
     def _setup(self, noise, num_output_frames):
+        self._join_context()          # a previous run's last context pass must not outlive its caches
         local_attn_cfg = _mk(self.args, "local_attn_size", -1)
         kv_cache_size = (local_attn_cfg if local_attn_cfg != -1 else num_output_frames) * self.frame_seq_length
         if self.verbose:
@@ -122,6 +161,7 @@ class CausalInferencePipeline(nn.Module):
                 output[:, start:start + nf] = denoised
             self._clean_context_pass(denoised, cond, start)
             yield start, denoised
+        self._join_context()
 
     @torch.no_grad()
     def stream_video(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None):
@@ -163,6 +203,7 @@ class CausalInferencePipeline(nn.Module):
             self._clean_context_pass(denoised, cond, start)
             prof.block_end()
             start += nf
+        self._join_context()
         prof.stop("diffusion")
         prof.start("vae")
         video = None

@@ -24,6 +24,7 @@ class InteractiveCausalInferencePipeline(CausalInferencePipeline):
         """interactive_causal_inference.py:34-106: (optionally) zero the KV cache -- end indices are deliberately NOT
         reset (:43-44) --, re-encode the last <= local_attn_size generated frames in ONE forward at
         t = context_noise under the new prompt, and make the next forward rebuild the cross-attention K/V."""
+        self._join_context()          # the last block's context pass (aux stream) must be done before the caches are zeroed / rewritten
         if not self.global_sink:
             for cache in self.kv_cache1:
                 cache["k"].zero_()
@@ -79,6 +80,7 @@ class InteractiveCausalInferencePipeline(CausalInferencePipeline):
             self._clean_context_pass(denoised, cond, start)
             prof.block_end()
             start += nf
+        self._join_context()
         prof.stop("diffusion")
         prof.start("vae")
         video = None

@@ -43,6 +43,7 @@ class WanDiffusionWrapper(nn.Module):
         return self.scheduler
 
     supports_kv_only = True      # the pipelines pass kv_only=True for passes whose output they discard
+    supports_layer_events = True  # ... and layer_wait / layer_record to run two forwards one layer apart on two streams
 
     @torch.no_grad()
     def forward(self, noisy_image_or_video: torch.Tensor, conditional_dict: dict, timestep: torch.Tensor,
@@ -50,7 +51,7 @@ class WanDiffusionWrapper(nn.Module):
                 current_start: Optional[int] = None, classify_mode: Optional[bool] = False,
                 concat_time_embeddings: Optional[bool] = False, clean_x: Optional[torch.Tensor] = None,
                 aug_t: Optional[torch.Tensor] = None, cache_start: Optional[int] = None,
-                sink_recache_after_switch: bool = False, kv_only: bool = False):
+                sink_recache_after_switch: bool = False, kv_only: bool = False, layer_wait=None, layer_record=None):
         """noisy [B,F,16,H,W], timestep [B,F] -> (flow_pred, pred_x0), both [B,F,16,H,W].  kv_only (not in the reference's
         signature; default off): only update the KV caches, return (None, None) -- see CausalWanModelHIP.forward_frames."""
         if kv_cache is None or classify_mode or clean_x is not None:
@@ -62,7 +63,7 @@ class WanDiffusionWrapper(nn.Module):
         sigma = self.scheduler.sigma_of(t)                                              # wan_wrapper.py:195-197
         flow, x0 = self.model.forward_frames(x, t, prompt_embeds.to(dev), kv_cache, crossattn_cache,
                                              int(current_start or 0), sink_recache_after_switch, sigma=sigma,
-                                             kv_only=kv_only)
+                                             kv_only=kv_only, layer_wait=layer_wait, layer_record=layer_record)
         if kv_only:
             return None, None
         dt = noisy_image_or_video.dtype

@@ -258,3 +258,33 @@ def test_kv_only_context_pass_is_bit_identical():
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][3] == outs[1][3]
     for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
         assert torch.equal(a, b)
+
+
+def test_two_stream_context_overlap_is_bit_identical():
+    """The clean-context pass on the aux stream, one layer ahead of the next block's first forward on the main stream
+    (per-layer events), against everything on one stream: same latents, same caches, same indices -- single-prompt stream AND
+    the interactive pipeline (recache joins the aux stream first), run twice to catch an ordering that only holds by luck."""
+    from longlive_amd.pipeline import CausalInferencePipeline, InteractiveCausalInferencePipeline
+    cfg, gen, enc = _pipe_generator()
+    noise = synth.synth_noise(cfg, 18, seed=45, device=DEV)
+
+    def run(overlap, interactive):
+        cls = InteractiveCausalInferencePipeline if interactive else CausalInferencePipeline
+        P = cls(_pipe_args(False), DEV, generator=gen, text_encoder=enc)
+        P.overlap_context = overlap
+        P.randn_like = TD.HashRandn(47)
+        if interactive:
+            _, lat = P.inference(noise, text_prompts_list=[["p0"], ["p1"]], switch_frame_indices=[7], return_latents=True)
+        else:
+            _, lat = P.inference(noise, ["p0"], return_latents=True)
+        torch.cuda.synchronize()
+        return (lat.clone(), [kv["k"].clone() for kv in P.kv_cache1] + [kv["v"].clone() for kv in P.kv_cache1],
+                (P.kv_cache1[0]["global_end_index"], P.kv_cache1[0]["local_end_index"]))
+
+    for interactive in (False, True):
+        base = run(False, interactive)
+        for rep in range(2):
+            got = run(True, interactive)
+            assert torch.equal(got[0], base[0]) and got[2] == base[2], (interactive, rep)
+            for a, b in zip(got[1], base[1]):
+                assert torch.equal(a, b), (interactive, rep)
