@@ -392,8 +392,8 @@ def run_replica(args, rank, world, local_rank, sync):
     if os.environ.get("LL_FUSE_V") == "0":
         gen.model.fuse_v_insert = False
     pipe = CausalInferencePipeline(_pipe_args(), dev, generator=gen)
-    if os.environ.get("LL_OVERLAP") == "0":                            # A/B only: context pass on the main stream
-        pipe.overlap_context = False
+    if os.environ.get("LL_OVERLAP") == "1":                            # opt-in: context pass on a second stream (+0.65 %)
+        pipe.overlap_context = True
     extra_blocks = 0 if (args.no_extras or rank != 0) else 1           # one more steady-state block for the kernels table
     nblocks = args.warmup + args.steps + extra_blocks
     T = 3 * nblocks
