@@ -914,6 +914,8 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_sk_combine_kernel(const fl
 }
 
 static int g_attn_variant = 2;   // 0: simple kernel, 1: software-pipelined, 2: + ping-pong wave groups for long key ranges
+static int g_attn_pp_min_keys = 16 * KT;   // key ranges at least this long run the ping-pong loop (cross-attention's 512 keys: one-barrier loop)
+void ll_set_attn_pp_min_internal(int v) { g_attn_pp_min_keys = v; }
 static int g_attn_xcd = 1;
 // stream-K: -1 = off (DEFAULT), 0 = auto (one workgroup per CU when it shortens the walk), N > 0 = force N workgroups.
 // Off by default because it LOSES on this chip although it removes the idle CUs: interleaved A/B of bench.py on one device,
@@ -939,7 +941,7 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
   }
   int nqt = (Lq + NW * 32 - 1) / (NW * 32);
   dim3 grid(nqt * H, 1, B), block(NW * 64);
-  if (g_attn_variant >= 2 && nkeys >= 16 * KT)   // short ranges (cross-attention, 512 keys): the one-barrier loop is faster
+  if (g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys)   // short ranges (cross-attention, 512 keys): the one-barrier loop is faster
     hipLaunchKernelGGL((flash_attn_pipe_kernel<NW, 1>), grid, block, (PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B,
                        (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
                        k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
@@ -989,7 +991,7 @@ extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_l
   if (n1 > 0 && seg_adjacent) { n0 += n1; n1 = 0; }
   if (g_attn_variant >= 1 && n1 == 0) {
     int nqt = (Lq + 255) / 256;
-    bool pp = g_attn_variant >= 2 && n0 >= 16 * KT;
+    bool pp = g_attn_variant >= 2 && n0 >= g_attn_pp_min_keys;
     int W = have_workspace ? attn_sk_workgroups(B, Lq, H, n0, 1LL << 40, attn_num_cus()) : 0;
     if (W > 0)
       snprintf(out, (size_t)cap, "flash_attn_sk_kernel<8> (ping-pong wave groups, stream-K), %d workgroups x %lld key tiles + "

@@ -73,26 +73,37 @@ class _Conv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cfg.dim, device=device, dtype=dtype), requires_grad=False)
 
 
+def _idx_versions(cache: dict):
+    g, e = cache.get("global_end_index"), cache.get("local_end_index")      # host ints: the value itself is the "version"
+    return (g._version if torch.is_tensor(g) else ("int", g), e._version if torch.is_tensor(e) else ("int", e))
+
+
 def _kv_state(cache: dict) -> Tuple[int, int]:
-    """(global_end_index, local_end_index) as python ints.  Accepts the reference's cache dicts
-    (int64[1] device tensors, pipeline/causal_inference.py:275-276): they are read back ONCE and shadowed under
-    `_ll_idx`; afterwards the shadow is authoritative and the tensors are only written (async fill_)."""
+    """(global_end_index, local_end_index) as python ints.  Accepts the reference's cache dicts (int64[1] device tensors,
+    pipeline/causal_inference.py:275-276): they are read back ONCE and shadowed under `_ll_idx`; afterwards the shadow is
+    authoritative and the tensors are only written (async fill_) -- unless somebody ELSE writes them: the reference's training
+    pipelines reset them in place (`blk["global_end_index"].zero_()`, pipeline/streaming_training.py:290-305).  Every in-place
+    write bumps the tensor's version counter, so a version that is not the one left by our own last fill_ means an external
+    write, and the tensors are read again (one sync, only then)."""
     st = cache.get("_ll_idx")
+    if st is not None and len(st) == 4 and st[2:] != list(_idx_versions(cache)):
+        st = None
     if st is None:
         g, e = cache["global_end_index"], cache["local_end_index"]
-        st = [int(g.item()) if torch.is_tensor(g) else int(g), int(e.item()) if torch.is_tensor(e) else int(e)]
+        st = [int(g.item()) if torch.is_tensor(g) else int(g), int(e.item()) if torch.is_tensor(e) else int(e),
+              *_idx_versions(cache)]
         cache["_ll_idx"] = st
     return st[0], st[1]
 
 
 def _kv_commit(cache: dict, G: int, E: int) -> None:
-    cache["_ll_idx"] = [G, E]
     for key, val in (("global_end_index", G), ("local_end_index", E)):
         cur = cache.get(key)
         if torch.is_tensor(cur):
             cur.fill_(val)
         else:
             cache[key] = val
+    cache["_ll_idx"] = [G, E, *_idx_versions(cache)]
 
 
 class CausalWanModelHIP(nn.Module):

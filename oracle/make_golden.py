@@ -505,6 +505,71 @@ def gen_pipe_calls(ns):
 
 
 # --------------------------------------------------------------------------------------------
+TRAIN_CASES = (  # tag, class, chunks [(frames, start, kwargs)], ctor kwargs
+    ("plain", "train", dict(last_step_only=False, context_noise=0), [(6, 0, {}), (9, 6, {})]),
+    ("last_step_ctx", "train", dict(last_step_only=True, context_noise=100), [(6, 0, {})]),
+    ("switch_mid", "switch", dict(last_step_only=False, context_noise=0), [(6, 0, {}), (12, 6, dict(switch=6))]),
+    ("switch_ext", "switch", dict(last_step_only=False, context_noise=50), [(9, 30, dict(switch=3, ext=24))]),
+    ("switch_none", "switch", dict(last_step_only=True, context_noise=0), [(6, 0, dict(switch=None))]),
+    ("switch_at0", "switch", dict(last_step_only=False, context_noise=0), [(6, 0, dict(switch=0))]),
+)
+
+
+def run_train_case(classes, fg, kind, ctor, chunks, cfg, randn_patch):
+    """Drives one TRAIN_CASES entry; shared with tests/test_pipeline_host.py (which passes longlive_amd's classes)."""
+    cls = classes[kind]
+    P = cls(denoising_step_list=[1000, 750, 500, 250], scheduler=fg.scheduler, generator=fg, num_frame_per_block=3,
+            same_step_across_blocks=False, local_attn_size=12, slice_last_frames=21, **ctor)
+    P.num_transformer_blocks, P.frame_seq_length = 2, 4
+    P.kv_cache_size = (12 + 21) * 4
+    P._initialize_kv_cache(1, torch.bfloat16, "cpu")
+    P._initialize_crossattn_cache(1, torch.bfloat16, "cpu")
+    randn_patch(P)
+    torch.manual_seed(11)                                   # exit steps: torch.randint on the CPU generator
+    enc = lambda name: {"prompt_embeds": torch.zeros(1, 1), "name": name}
+    outs, infos = [], []
+    for ci, (frames, start, kw) in enumerate(chunks):
+        noise = synth.synth_noise(cfg, frames, seed=3 + ci)
+        args = dict(noise=noise, conditional_dict=enc("p0"), current_start_frame=start, requires_grad=False)
+        if "switch" in kw:
+            args.update(switch_frame_index=kw["switch"], switch_conditional_dict=enc("p1") if kw["switch"] is not None else None)
+            if "ext" in kw:
+                args["switch_recache_frames"] = synth.synth_noise(cfg, kw["ext"], seed=17)
+        res = P.generate_chunk_with_cache(**args)
+        outs.append(res[0].clone())
+        infos.append(tuple(res[1:]))
+    P.clear_kv_cache()
+    cleared = dict(k0=float(P.kv_cache1[0]["k"].abs().sum()), g=int(P.kv_cache1[0]["global_end_index"]),
+                   ca=bool(P.crossattn_cache[0]["is_init"]))
+    return dict(log=fg.log, outs=outs, infos=infos, cleared=cleared)
+
+
+def gen_train_calls(ns):
+    """Reference StreamingTrainingPipeline / StreamingSwitchTrainingPipeline (pipeline/streaming_training.py,
+    pipeline/streaming_switch_training.py) driving the fake generator with requires_grad=False."""
+    import importlib
+    st = importlib.import_module("pipeline.streaming_training")
+    sw = importlib.import_module("pipeline.streaming_switch_training")
+    classes = {"train": st.StreamingTrainingPipeline, "switch": sw.StreamingSwitchTrainingPipeline}
+    sch = ns.scheduler.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    cfg = synth.WanConfig(lat_h=4, lat_w=4)
+    rec = {}
+    real = torch.randn_like
+    try:
+        for tag, kind, ctor, chunks in TRAIN_CASES:
+            fg = FakeGenerator(sch, 4)
+
+            def patch(P):
+                torch.randn_like = _HashRandn(5)
+            rec[tag] = run_train_case(classes, fg, kind, ctor, chunks, cfg, patch)
+            torch.randn_like = real
+    finally:
+        torch.randn_like = real
+    _save("train_calls.pt", rec)
+
+
+# --------------------------------------------------------------------------------------------
 def gen_vae(ns):
     """Reference WanVAE_ decoder (wan/modules/vae.py) through the reference WanVAEWrapper.decode_to_pixel code path, with
     synthetic weights: full decode of 5 latent frames at 8x12 latents (64x96 pixels, 17 frames), and the streaming

@@ -42,21 +42,24 @@ def _idx(c):
     return int(c["global_end_index"]), int(c["local_end_index"])
 
 
-@pytest.mark.parametrize("tag", ["single", "inter_gs0", "inter_gs1"])
+@pytest.mark.parametrize("tag", ["single", "inter_gs0", "inter_gs1", "train:plain", "train:switch_mid", "train:switch_ext"])
 def test_reference_call_log_on_reference_cache_objects(tag):
+    """`train:*` = the call logs of the reference's training roll-out pipelines (tests/golden/train_calls.pt): a cache of
+    (local_attn_size + 21) frames read through a 12-frame window (pipeline/streaming_training.py:49-50)."""
     from longlive_amd.wan_wrapper import WanDiffusionWrapper
-    rec = load_golden("pipe_calls.pt")[tag]
+    train = tag.startswith("train:")
+    rec = load_golden("train_calls.pt")[tag[6:]] if train else load_golden("pipe_calls.pt")[tag]
     log = rec["log"]
     cfg = synth.WanConfig(num_layers=2, lat_h=4, lat_w=4, local_attn_size=12, sink_size=3)
     fs = cfg.frame_seqlen
-    assert fs == 4 and log[0]["n_layers"] == 2 and log[0]["kv_shape"] == [1, 12 * fs, 12, 128]
-    S = 12 * fs
+    S = (33 if train else 12) * fs
+    assert fs == 4 and log[0]["n_layers"] == 2 and log[0]["kv_shape"] == [1, S, 12, 128]
     sd = synth.synth_state_dict(cfg, seed=21)
     gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=DEV,
                               state_dict={k: v.to(DEV) for k, v in sd.items()})
     for mod in gen.model.modules():
         if hasattr(mod, "max_attention_size"):
-            mod.max_attention_size = S
+            mod.max_attention_size = 12 * fs
     prompts = {f"p{i}": synth.synth_prompt_embeds(cfg, seed=31 + i) for i in range(4)}
     # oracle (CPU): the reference's arithmetic and state machine restated, pinned bit-exact to the reference's own traces
     om = RM.RefModel(RM.RefConfig.from_cfg(cfg), sd, frame_seqlen_for_max_attn=fs)
@@ -111,3 +114,62 @@ def test_reference_call_log_on_reference_cache_objects(tag):
         assert torch.equal(za, zo), "slot occupancy differs from the oracle"
         assert rel_l2(ca_["k"].cpu(), co_["k"]) < 2e-2 and rel_l2(ca_["v"].cpu(), co_["v"]) < 2e-2
     print(f"{tag}: {len(log)} calls, worst x0 relL2 vs oracle {worst:.2e}, final indices {seq['ref'][-1]}")
+
+
+class _OracleGen:
+    """oracle RefGenerator behind the reference generator's keyword signature (CPU)."""
+    supports_kv_only = False
+
+    def __init__(self, og, model_ns):
+        self.og, self.model = og, model_ns
+
+    def __call__(self, noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache, current_start, **kw):
+        return self.og(noisy_image_or_video, conditional_dict["prompt_embeds"], timestep.float(), kv_cache, crossattn_cache,
+                       current_start, False)
+
+
+def test_training_rollout_pipeline_on_the_hip_generator():
+    """StreamingSwitchTrainingPipeline (forward-only mirror of pipeline/streaming_switch_training.py) end to end on the HIP
+    generator: two chunks on one persistent cache, the second with a mid-chunk prompt switch recached from the previous
+    chunk's frames; against the same pipeline class driving the CPU oracle."""
+    from types import SimpleNamespace
+    import trace_driver as TD
+    from longlive_amd.pipeline import StreamingSwitchTrainingPipeline
+    from longlive_amd.wan_wrapper import WanDiffusionWrapper
+    from oracle import ref_ops as R
+    cfg = synth.WanConfig(num_layers=2, lat_h=4, lat_w=4, local_attn_size=12, sink_size=3)
+    fs = cfg.frame_seqlen
+    sd = synth.synth_state_dict(cfg, seed=21)
+    gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=DEV,
+                              state_dict={k: v.to(DEV) for k, v in sd.items()})
+    om = RM.RefModel(RM.RefConfig.from_cfg(cfg), sd, frame_seqlen_for_max_attn=fs)
+    ons = SimpleNamespace(local_attn_size=12, max_attention_size=0, block_mask=None, named_modules=lambda: [],
+                          _prepare_blockwise_causal_attn_mask=lambda **kw: None)
+    ogen = _OracleGen(RM.RefGenerator(om, 5.0), ons)
+    prompts = [synth.synth_prompt_embeds(cfg, seed=31 + i) for i in range(2)]
+    outs = {}
+    for name, g, dev in (("hip", gen, DEV), ("oracle", ogen, "cpu")):
+        P = StreamingSwitchTrainingPipeline(denoising_step_list=[1000, 750, 500, 250], scheduler=R.FlowMatchSchedulerRef(5.0),
+                                            generator=g, num_frame_per_block=3, local_attn_size=12, slice_last_frames=21)
+        P.num_transformer_blocks, P.frame_seq_length, P.kv_cache_size = 2, fs, 33 * fs
+        if name == "hip":
+            assert (P.num_heads, P.head_dim, P.text_len) == (12, 128, 512)
+            P._initialize_kv_cache(1, bf, dev)
+            P._initialize_crossattn_cache(1, bf, dev)
+        else:
+            P.kv_cache1 = RM.new_kv_cache(1, 33 * fs, 2, 12, 128)
+            P.crossattn_cache = RM.new_crossattn_cache(1, 512, 2, 12, 128)
+        P.randn_like = TD.HashRandn(5)
+        torch.manual_seed(11)
+        P.randint = lambda low, high, size, device: torch.randint(low=low, high=high, size=size)     # CPU draw for both
+        c = [{"prompt_embeds": p.to(dev)} for p in prompts]
+        a, *_ = P.generate_chunk_with_cache(synth.synth_noise(cfg, 6, seed=3).to(dev), c[0], current_start_frame=0, requires_grad=False)
+        b, *_ = P.generate_chunk_with_cache(synth.synth_noise(cfg, 9, seed=4).to(dev), c[0], current_start_frame=6, requires_grad=False,
+                                            switch_frame_index=3, switch_conditional_dict=c[1], switch_recache_frames=a)
+        outs[name] = (a.cpu(), b.cpu(), [(int(k["global_end_index"]), int(k["local_end_index"])) for k in P.kv_cache1],
+                      P.kv_cache1[0]["k"].float().cpu())
+        if name == "hip":
+            assert g.model.max_attention_size == 12 * fs
+    assert outs["hip"][2] == outs["oracle"][2]
+    for i in (0, 1, 3):
+        assert rel_l2(outs["hip"][i], outs["oracle"][i]) < 2e-2, i

@@ -49,9 +49,16 @@ def test_reference_cache_dicts_with_tensor_indices():
              "global_end_index": torch.tensor([5]), "local_end_index": torch.tensor([3])}
     assert _kv_state(cache) == (5, 3)
     _kv_commit(cache, 9, 7)
-    assert int(cache["global_end_index"]) == 9 and int(cache["local_end_index"]) == 7 and cache["_ll_idx"] == [9, 7]
-    cache["global_end_index"].fill_(123)          # a stale device value must not override the shadow
-    assert _kv_state(cache) == (9, 7)
+    assert int(cache["global_end_index"]) == 9 and int(cache["local_end_index"]) == 7 and cache["_ll_idx"][:2] == [9, 7]
+    assert _kv_state(cache) == (9, 7)             # our own fill_ does not invalidate the shadow (no sync per forward)
+    # an EXTERNAL in-place write (the reference's training pipelines: clear_kv_cache() zeroes the index tensors,
+    # pipeline/streaming_training.py:290-305) is seen through the tensors' version counters and re-read
+    cache["global_end_index"].zero_()
+    cache["local_end_index"].zero_()
+    assert _kv_state(cache) == (0, 0)
+    _kv_commit(cache, 4, 4)
+    cache["local_end_index"].fill_(2)
+    assert _kv_state(cache) == (4, 2)
     ours = {"global_end_index": 0, "local_end_index": 0}
     _kv_commit(ours, 4, 4)
     assert ours["global_end_index"] == 4 and _kv_state(ours) == (4, 4)

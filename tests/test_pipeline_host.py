@@ -77,6 +77,49 @@ def test_call_sequence_matches_reference_pipeline(tag):
     assert torch.equal(lat, rec["latents"])
 
 
+@pytest.mark.parametrize("tag", ["plain", "last_step_ctx", "switch_mid", "switch_ext", "switch_none", "switch_at0"])
+def test_training_rollout_call_sequence_matches_reference(tag):
+    """Forward-only mirrors of the reference's training roll-out pipelines (requires_grad=False): same generator calls, outputs,
+    return values and clear_kv_cache effects as pipeline/streaming_training.py / streaming_switch_training.py
+    (tests/golden/train_calls.pt, oracle/make_golden.py::gen_train_calls)."""
+    from oracle.make_golden import TRAIN_CASES, run_train_case
+    from longlive_amd.pipeline import StreamingSwitchTrainingPipeline, StreamingTrainingPipeline
+    rec = load_golden("train_calls.pt")[tag]
+    _, kind, ctor, chunks = next(c for c in TRAIN_CASES if c[0] == tag)
+    fg = FakeGenerator(R.FlowMatchSchedulerRef(5.0), 4)
+
+    def patch(P):
+        P.randn_like = TD.HashRandn(5)
+    got = run_train_case({"train": StreamingTrainingPipeline, "switch": StreamingSwitchTrainingPipeline}, fg, kind, ctor, chunks,
+                         synth.WanConfig(lat_h=4, lat_w=4), patch)
+    assert len(got["log"]) == len(rec["log"])
+    for i, (a, b) in enumerate(zip(got["log"], rec["log"])):
+        assert a == b, f"call {i}: {a} != {b}"
+    for a, b in zip(got["outs"], rec["outs"]):
+        assert torch.equal(a, b)
+    assert got["infos"] == rec["infos"] and got["cleared"] == rec["cleared"]
+
+
+def test_training_rollout_is_forward_only_and_reports_exit_steps():
+    from longlive_amd.pipeline import StreamingTrainingPipeline
+    sch = R.FlowMatchSchedulerRef(5.0)
+    fg = FakeGenerator(sch, 4)
+    steps = torch.tensor([1000, 750, 500, 250])
+    P = StreamingTrainingPipeline(denoising_step_list=steps, scheduler=sch, generator=fg, same_step_across_blocks=True,
+                                  last_step_only=True, local_attn_size=12)
+    P.num_transformer_blocks, P.frame_seq_length, P.kv_cache_size = 2, 4, 33 * 4
+    P._initialize_kv_cache(1, torch.bfloat16, "cpu")
+    P._initialize_crossattn_cache(1, torch.bfloat16, "cpu")
+    noise = synth.synth_noise(synth.WanConfig(lat_h=4, lat_w=4), 3, seed=3)
+    cond = {"prompt_embeds": torch.zeros(1, 1), "name": "p"}
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        P.generate_chunk_with_cache(noise, cond)                      # requires_grad defaults to True upstream
+    out, t_from, t_to, sim = P.generate_chunk_with_cache(noise, cond, requires_grad=False, return_sim_step=True)
+    want_from = 1000 - int(torch.argmin((sch.timesteps.float() - 250.0).abs()))     # streaming_training.py:231-235
+    assert (t_from, t_to, sim) == (want_from, 0, 4) and len(fg.log) == 5
+    assert P.generator.model.max_attention_size == 12 * 4
+
+
 def test_stream_yields_blocks_and_matches_inference():
     cfg = synth.WanConfig(lat_h=4, lat_w=4)
     enc = lambda text_prompts: {"prompt_embeds": torch.zeros(1, 1), "name": text_prompts[0]}
