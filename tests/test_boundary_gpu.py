@@ -149,8 +149,8 @@ def test_training_rollout_pipeline_on_the_hip_generator():
     prompts = [synth.synth_prompt_embeds(cfg, seed=31 + i) for i in range(2)]
     outs = {}
     for name, g, dev in (("hip", gen, DEV), ("oracle", ogen, "cpu")):
-        P = StreamingSwitchTrainingPipeline(denoising_step_list=[1000, 750, 500, 250], scheduler=R.FlowMatchSchedulerRef(5.0),
-                                            generator=g, num_frame_per_block=3, local_attn_size=12, slice_last_frames=21)
+        P = StreamingSwitchTrainingPipeline(denoising_step_list=[1000, 750, 500, 250],
+                                            scheduler=g.get_scheduler() if name == "hip" else R.FlowMatchSchedulerRef(5.0), generator=g, num_frame_per_block=3, local_attn_size=12, slice_last_frames=21)
         P.num_transformer_blocks, P.frame_seq_length, P.kv_cache_size = 2, fs, 33 * fs
         if name == "hip":
             assert (P.num_heads, P.head_dim, P.text_len) == (12, 128, 512)
