@@ -60,6 +60,20 @@ __device__ __forceinline__ void tile_range(const Segs& sg, int t, int& base, int
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
+// Diagnostic build only (-DLL_ATTN_DIAG=bits, tools/attn_diag.hip; never defined for the shipped library): in-kernel clock
+// stamps around the ping-pong main loop (s_memtime = shader cycles, s_memrealtime = 100 MHz) and switches that drop one part of
+// the loop at a time (results are wrong by construction): 2 = no K/V staging in the loop, 4 = no softmax phase, 8 = no matrix
+// phase, 16 = no wait for the staged tile.
+#ifdef LL_ATTN_DIAG
+__device__ unsigned long long g_attn_diag[4 * 2048];
+extern "C" int ll_attn_diag_read(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_diag), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define DIAG_ON(bit) ((LL_ATTN_DIAG) & (bit))
+#else
+#define DIAG_ON(bit) 0
+#endif
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
                                                                 const bf16* __restrict__ Vc, bf16* __restrict__ O,
@@ -360,12 +374,17 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
     dma_vch[i] = (pos ^ ((key & 3) << 2)) * 16;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-#define PIPE_DMA(T, KS, VS)                                                                      \
-  {                                                                                              \
+#ifndef LL_ATTN_PRIO
+#define LL_ATTN_PRIO 0           // experiment: 0 = matrix phase at priority 1 (shipped), 1 = no priorities, 2 = softmax phase at priority 1
+#endif
+#define PIPE_DMA_SETUP(T)                                                                        \
     int t_ = (T) < nt ? (T) : nt - 1;                                                            \
     int valid_ = (t_ == nt - 1) ? last_valid : KT;                                               \
     const char* kt_ = reinterpret_cast<const char*>(kh) + (size_t)t_ * KT * ldk * 2;            \
-    const char* vt_ = reinterpret_cast<const char*>(vh) + (size_t)t_ * KT * ldk * 2;            \
+    const char* vt_ = reinterpret_cast<const char*>(vh) + (size_t)t_ * KT * ldk * 2;
+#define PIPE_DMA(T, KS, VS)                                                                      \
+  {                                                                                              \
+    PIPE_DMA_SETUP(T)                                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < NDMA; ++i_) {                                        \
       int key_ = dma_key[i_] < valid_ ? dma_key[i_] : valid_ - 1;                                \
       unsigned row_ = (unsigned)key_ * (unsigned)ldk * 2u;                                       \
@@ -512,6 +531,7 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
     }
   } else {
     // SM(t): softmax of S(t) in s_cur -> P(t) in pw, running max / sum, O rescale.  VALU + transcendental only.
+#define LL_EXP2(x) (DIAG_ON(32) ? (x) : __builtin_amdgcn_exp2f(x))
 #define PP_SM(T)                                                                                 \
   {                                                                                              \
     if ((T) == nt - 1 && last_valid < KT) {                                                      \
@@ -533,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                           \
       float p[8];                                                                                \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
-        p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));            \
+        p[j] = LL_EXP2(__builtin_fmaf(s_cur[kb][8 * s2 + j], c, -mc));                           \
         rs += p[j];                                                                              \
       }                                                                                          \
       pw[kb][s2] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), \
@@ -577,16 +597,21 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
     const bool own_block = xcd_placement >= 0 && qtile * (NW * 32) + wave_u * 32 < Lq;   // ... and false for waves whose 32 query rows are all padding
                                                             // (last q-tile): they only stage and sync -- the chip runs at
                                                             // its power cap, an idle wave is clock for the others
+#ifdef LL_ATTN_DIAG
+    unsigned long long dg0 = __builtin_amdgcn_s_memtime(), dr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (late) __syncthreads();
     int kq = 1, kd = 2, vq = 0, vd = 2;      // slots: K(t+1), K(t+2), V(t), V(t+2)
     for (int t = 0; t < nt; ++t) {
-      PIPE_DMA(t + 2, kd, vd);
-      if (own_block) PP_SM(t);
+      if (!DIAG_ON(2)) PIPE_DMA(t + 2, kd, vd);
+      if (own_block && !DIAG_ON(4)) PP_SM(t);
       __syncthreads();
-      __builtin_amdgcn_s_setprio(1);      // MM is the longer phase: its MFMA / LDS issue wins over the partner's softmax VALU
-      if (own_block) PP_MM(vq, kq);
-      __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (LL_ATTN_PRIO == 0) __builtin_amdgcn_s_setprio(1);      // MM is the longer phase: its MFMA / LDS issue wins over the partner's softmax VALU
+      if (LL_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      if (own_block && !DIAG_ON(8)) PP_MM(vq, kq);
+      if (LL_ATTN_PRIO == 0) __builtin_amdgcn_s_setprio(0);
+      if (LL_ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+      if (!DIAG_ON(16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       kq = kd;
       kd = kd == KSTAGES - 1 ? 0 : kd + 1;
@@ -594,6 +619,13 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
       vd = vd == VSTAGES - 1 ? 0 : vd + 1;
     }
     if (!late) __syncthreads();
+#ifdef LL_ATTN_DIAG
+    if (tid == 0 && blockIdx.x < 2048) {
+      g_attn_diag[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memtime() - dg0;
+      g_attn_diag[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - dr0;
+      g_attn_diag[4 * blockIdx.x + 2] = nt;
+    }
+#endif
 #undef PP_SM
 #undef PP_MM
   }
@@ -913,7 +945,10 @@ __global__ __launch_bounds__(NW * 64) void flash_attn_sk_combine_kernel(const fl
   }
 }
 
-static int g_attn_variant = 2;   // 0: simple kernel, 1: software-pipelined, 2: + ping-pong wave groups for long key ranges
+#ifndef LL_ATTN_VARIANT_DEFAULT
+#define LL_ATTN_VARIANT_DEFAULT 2
+#endif
+static int g_attn_variant = LL_ATTN_VARIANT_DEFAULT;   // 0: simple kernel, 1: software-pipelined, 2: + ping-pong wave groups for long key ranges
 static int g_attn_pp_min_keys = 16 * KT;   // key ranges at least this long run the ping-pong loop (cross-attention's 512 keys: one-barrier loop)
 void ll_set_attn_pp_min_internal(int v) { g_attn_pp_min_keys = v; }
 static int g_attn_xcd = 1;
