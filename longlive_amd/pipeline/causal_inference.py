@@ -166,18 +166,52 @@ class CausalInferencePipeline(nn.Module):
         self._join_context()
 
     @torch.no_grad()
-    def stream_video(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None):
+    def stream_video(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None,
+                     overlap_decode: bool = False):
         """Live form of `inference`: yields (start_frame, pixels[B, T', 3, H, W] in [0, 1]) after every block, decoding
         each block with the VAE's streaming cache (WanVAE_.cached_decode, wan/modules/vae.py:571-593) -- the first block
-        gives 1 + 4 (F - 1) frames, later ones 4 F.  The concatenation equals `inference(...)`'s video bit for bit."""
+        gives 1 + 4 (F - 1) frames, later ones 4 F.  The concatenation equals `inference(...)`'s video bit for bit.
+
+        overlap_decode: block i is decoded on a second HIP stream while block i + 1 is generated on the caller's stream (the
+        decoder's staging-bound convolutions run beside the power-bound DiT kernels); block i's pixels are then yielded after
+        block i + 1's generation has been queued, i.e. one block later, with the caller's stream made to wait for that decode.
+        Same values, same order."""
         if self.vae is None:
             raise RuntimeError("stream_video needs a VAE (pass vae= to the pipeline)")
         self.vae.model.clear_cache()
+        pending = None                                   # (start, pixels, event) of the block being decoded on the side stream
+        side = None
         try:
             for start, latents in self.stream(noise, text_prompts, output=output):
-                video = self.vae.decode_to_pixel(latents, use_cache=True)
-                yield start, (video * 0.5 + 0.5).clamp(0, 1)
+                if not (overlap_decode and latents.is_cuda):
+                    video = self.vae.decode_to_pixel(latents, use_cache=True)
+                    yield start, (video * 0.5 + 0.5).clamp(0, 1)
+                    continue
+                main = torch.cuda.current_stream(latents.device)
+                if side is None:
+                    side = torch.cuda.Stream(device=latents.device)
+                side.wait_stream(main)                   # the block's denoised latents are final (the context pass only reads them)
+                latents.record_stream(side)
+                with torch.cuda.stream(side):            # decodes are ordered among themselves by the side stream (streaming cache)
+                    video = self.vae.decode_to_pixel(latents, use_cache=True)
+                    video = (video * 0.5 + 0.5).clamp(0, 1)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                if pending is not None:
+                    ps, pv, pe = pending
+                    main.wait_event(pe)
+                    pv.record_stream(main)
+                    yield ps, pv
+                pending = (start, video, ev)
+            if pending is not None:
+                ps, pv, pe = pending
+                torch.cuda.current_stream(pv.device).wait_event(pe)
+                pv.record_stream(torch.cuda.current_stream(pv.device))
+                pending = None
+                yield ps, pv
         finally:
+            if side is not None:
+                torch.cuda.current_stream(side.device).wait_stream(side)
             self.vae.model.clear_cache()
 
     @torch.no_grad()

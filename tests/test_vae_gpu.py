@@ -183,6 +183,12 @@ def test_pipeline_streams_pixels_identical_to_one_shot_decode(vae):
     pieces = [px for _, px in P.stream_video(noise, ["p0"])]
     assert [p.shape[1] for p in pieces] == [9, 12, 12]
     assert torch.equal(torch.cat(pieces, 1), video)
+    # decode on a second stream beside the next block's generation: same frames, same order, one block later
+    P.randn_like = TM.TD.HashRandn(43)
+    got = [(st, px) for st, px in P.stream_video(noise, ["p0"], overlap_decode=True)]
+    torch.cuda.synchronize()
+    assert [st for st, _ in got] == [0, 3, 6]
+    assert torch.equal(torch.cat([px for _, px in got], 1), video)
 
 
 def test_vae_first_frame_at_real_resolution_matches_oracle(vae):

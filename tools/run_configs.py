@@ -5,7 +5,7 @@
             configs/longlive_interactive_inference.yaml:21-27) exercising KV-recache on every switch.
   config 5: `960 --quant int8 --only single`: 240-s generation (T = 960, RoPE frame index < 1024) with W8A8 block linears,
             one replica of the 8 that BASELINE config 5 runs side by side (replicas share nothing: bench.py --gpus 8)
-  e2e     : with `--vae`, the same single-prompt stream with every block decoded live by the HIP VAE decoder
+  e2e     : with `--vae` (`--e2e-only` skips configs 3 / 4), the same single-prompt stream with every block decoded live by the HIP VAE decoder
             (pipeline.stream_video): generated pixel frames/s including the decode, and the latency of each block's frames.
 Random-init LongLive-1.3B / Wan-VAE weights, synthetic prompt embeddings / noise (longlive_amd.synth)."""
 import json
@@ -46,6 +46,8 @@ def main():
     noise = synth.synth_noise(cfg, T, seed=0, device=dev)
     out = {"T_latent": T, "pixel_frames": 4 * T, "quant": quant or "bf16"}
 
+    if "--e2e-only" in sys.argv:
+        return e2e(T, dev, gen, enc, noise, out)
     P = CausalInferencePipeline(args(True), dev, generator=gen, text_encoder=enc)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     _, lat = P.inference(noise, ["p0"], return_latents=True, profile=True)
@@ -73,6 +75,10 @@ def main():
         "switch_latency_ms": pr.get("switch_latency_ms"), "finite": bool(torch.isfinite(lat.float()).all()),
         "latent_std": float(lat.float().std()),
         "end_indices": [I.kv_cache1[0]["global_end_index"], I.kv_cache1[0]["local_end_index"]]}
+    e2e(T, dev, gen, enc, noise, out)
+
+
+def e2e(T, dev, gen, enc, noise, out):
     if "--vae" in sys.argv:
         from longlive_amd.vae import WanVAEWrapper
         vcfg = synth.VaeConfig()
@@ -80,18 +86,23 @@ def main():
         vae.load_state_dict(synth.synth_vae_state_dict(vcfg, seed=5, device=dev))
         P = CausalInferencePipeline(args(True), dev, generator=gen, text_encoder=enc, vae=vae)
         Te = min(T, 60)
-        times, frames = [], 0
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _, px in P.stream_video(noise[:, :Te], ["p0"]):
+        for key, overlap in (("e2e_stream_video", False), ("e2e_stream_video_overlap_decode", True)):
+            times, frames = [], 0
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _, px in P.stream_video(noise[:, :Te], ["p0"], overlap_decode=overlap):
+                if not overlap:
+                    torch.cuda.synchronize()
+                else:
+                    px[0, -1, 0, 0, 0].item()                  # wait for THIS block's pixels only (the next block keeps running)
+                times.append(time.perf_counter()); frames += px.shape[1]
             torch.cuda.synchronize()
-            times.append(time.perf_counter()); frames += px.shape[1]
-        dt = times[-1] - t0
-        steady = [(b - a) * 1e3 for a, b in zip(times[5:-1], times[6:])]       # full window from block 6 on
-        out["e2e_stream_video"] = {
-            "T_latent": Te, "pixel_frames": frames, "wall_s": dt, "fps_overall": frames / dt,
-            "steady_ms_per_block": sum(steady) / max(1, len(steady)),
-            "fps_steady_with_vae": 12e3 * len(steady) / sum(steady) if steady else None,
-            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            dt = time.perf_counter() - t0
+            steady = [(b - a) * 1e3 for a, b in zip(times[5:-1], times[6:])]       # full window from block 6 on
+            out[key] = {
+                "T_latent": Te, "pixel_frames": frames, "wall_s": dt, "fps_overall": frames / dt,
+                "steady_ms_per_block": sum(steady) / max(1, len(steady)),
+                "fps_steady_with_vae": 12e3 * len(steady) / sum(steady) if steady else None,
+                "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
     print(json.dumps(out))
 
 
