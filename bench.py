@@ -378,9 +378,7 @@ def run_replica(args, rank, world, local_rank, sync):
     from longlive_amd.pipeline import CausalInferencePipeline, InteractiveCausalInferencePipeline
     from longlive_amd.wan_wrapper import WanDiffusionWrapper
 
-    for kv in filter(None, os.environ.get("LL_TUNING", "").split(",")):   # kernel A/B only, e.g. LL_TUNING=attn_variant=2
-        k, v = kv.split("=")
-        _lib.check(_lib.load().ll_set_tuning(k.encode(), int(v)), "ll_set_tuning")
+    _lib.load()                                                        # applies LL_TUNING=key=value,... (kernel A/B only)
     cfg = synth.longlive_1_3b(local_attn_size=12, sink_size=3)
     sd = synth.synth_state_dict(cfg, seed=0, device=dev)               # random-init weights of the 1.3B architecture
     gen = WanDiffusionWrapper(timestep_shift=5.0, local_attn_size=12, sink_size=3, cfg=cfg, device=dev, state_dict=sd)

@@ -76,6 +76,10 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
+    for kv in filter(None, os.environ.get("LL_TUNING", "").split(",")):   # kernel A/B only, e.g. LL_TUNING=attn_variant=2,conv_halo=0
+        k, v = kv.split("=")
+        if lib.ll_set_tuning(k.encode(), int(v)) != 0:
+            raise RuntimeError(f"LL_TUNING: {lib.ll_last_error().decode()}")
     return lib
 
 

@@ -210,6 +210,155 @@ __global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 3x3x3 causal convolution with the input staged ONCE per (temporal tap, 32-channel slice) as a halo tile.
+//
+// The implicit GEMM above stages every shifted input pixel again for each of the 27 taps: 44 KiB of LDS-DMA per 64-deep K-step
+// against 768 MFMA cycles (N = 96), and the CU's LDS-DMA path (~35-50 B/clk) is what bounds it (31 % of the MFMA peak on the
+// six 96 -> 96 convolutions at 480 x 832 that are 70 % of the decoder's FLOPs).  Here a workgroup owns a 16 x 32 pixel tile of
+// one output frame and 96 output channels; for each (kt, 32-channel slice) it stages the (16+2) x (32+2) halo of that input
+// frame (38.3 KiB) and serves all nine spatial taps from it -- a tap is only a shifted LDS read address -- plus the 9 x 96 x 32
+// weights in three 18-KiB units (one per kh): 94 KiB staged per 1728 MFMAs per wave pair instead of 396 KiB.
+//   LDS: 2 halo slots x 39 KiB + 3 weight-unit slots x 18 KiB = 132 KiB; unit u = ((kt * nslice) + slice) * 3 + kh, two units
+//   staged ahead, one barrier per unit (72 MFMAs per wave).  Halo / weight rows are 64 B (32 channels); 16-byte part q of row j
+//   sits at position q ^ (((j >> 3) & 1) << 1): conflict-free ds_read_b128 fragments for 16-aligned runs of 16 rows.
+//   Waves: wave w owns image rows 2w, 2w+1 of the tile (4 blocks of 16 pixels) x 6 blocks of 16 channels = 96 accumulator
+//   registers; the accumulation order over K is (kt, slice, kh, kw) instead of (tap, channel) -- same products, fp32 sums in
+//   another order (parity bar unchanged: <= 2 bf16 ulp against fp32 conv3d).
+#define HL_TH 16
+#define HL_TW 32
+#define HL_HW (HL_TW + 2)
+#define HL_HALO_PX ((HL_TH + 2) * HL_HW)            // 612
+#define HL_HALO_PIECES ((HL_HALO_PX + 15) / 16)     // 39 (16 rows of 64 B per 1-KiB LDS-DMA piece)
+#define HL_HALO_B (HL_HALO_PIECES * 1024)
+#define HL_WUNIT_B (18 * 1024)                      // 3 kw x 96 co x 64 B
+#define HL_LDS (2 * HL_HALO_B + 3 * HL_WUNIT_B)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restrict__ x, const char* __restrict__ zero,
+                                                           const char* __restrict__ Wt, bf16* __restrict__ Y, int T, int H,
+                                                           int W, int Cin, int N, size_t wrow_bytes, int ldo, int tiles_w,
+                                                           int tiles_h, int ntn, EpiArgs ea) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const hsm = smem;
+  char* const wsm = smem + 2 * HL_HALO_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = lid % ntn;
+  int tile = lid / ntn;
+  const int tw = tile % tiles_w;
+  tile /= tiles_w;
+  const int th = tile % tiles_h, t = tile / tiles_h;
+  const int h0 = th * HL_TH, w0 = tw * HL_TW, n0 = nt * 96;
+  const long long fb = (long long)H * W * Cin * 2;
+  const int nslice = Cin >> 5, nu = 9 * nslice;
+
+  // ---- staging plan (loop invariant per lane): 5 halo pieces and 3 weight pieces per wave and unit; a wave without a fifth /
+  // third piece of its own re-issues its previous one (same bytes to the same place) so that every wave's vmcnt counts agree
+  int hoff[5];            // byte offset of the lane's 16-byte part inside frame (t - 2), channel slice 0; < 0: zero row
+  int hdst[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int p = wave + 8 * k;
+    p = p < HL_HALO_PIECES ? p : p - 8;
+    int j = 16 * p + (lane >> 2);
+    int hr = j / HL_HW, hc = j - hr * HL_HW;
+    int hy = h0 - 1 + hr, wx = w0 - 1 + hc;
+    bool ok = j < HL_HALO_PX && hy >= 0 && hy < H && wx >= 0 && wx < W;
+    int part = (lane & 3) ^ (((j >> 3) & 1) << 1);
+    hoff[k] = ok ? (hy * W + wx) * Cin * 2 + part * 16 : -1;
+    hdst[k] = p * 1024;
+  }
+  const char* wsrc[3];
+  int wdst[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int bpc = wave + 8 * k;
+    bpc = bpc < 18 ? bpc : bpc - 8;
+    int kw = bpc / 6, pp = bpc - 6 * kw;
+    int row = 16 * pp + (lane >> 2);
+    int part = (lane & 3) ^ (((row >> 3) & 1) << 1);
+    wsrc[k] = Wt + (size_t)(n0 + row) * wrow_bytes + (size_t)kw * Cin * 2 + part * 16;
+    wdst[k] = bpc * 1024;
+  }
+  const char* xt = x + (long long)(t - 2) * fb;
+  auto issue = [&](int u) {
+    int G = u / 3, kh = u - 3 * G;
+    int kt = G / nslice, sl = G - kt * nslice;
+    char* wb = wsm + (u % 3) * HL_WUNIT_B;
+    unsigned woff = (unsigned)(((kt * 9 + kh * 3) * Cin + sl * 32) * 2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[k] + woff), (lptr_t)(wb + wdst[k]), 16, 0, 0);
+    if (kh == 0) {
+      char* hb = hsm + (G & 1) * HL_HALO_B;
+      const char* xf = xt + (long long)kt * fb + sl * 64;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const char* src = hoff[k] >= 0 ? xf + hoff[k] : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(hb + hdst[k]), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[2][6][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[i][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment row indices: halo row j = (2 wave + i + kh) * 34 + 16 b + kw + fr; weight row = kw * 96 + 16 a + fr
+  const int jbase = (2 * wave) * HL_HW + fr;
+  const int wswz = ((fr >> 3) & 1) << 1;
+
+  issue(0);
+  if (nu > 1) issue(1);
+  for (int u = 0; u < nu; ++u) {
+    // unit u has landed; unit u + 1's pieces (3 weight, + 5 halo when it opens a group) may stay in flight
+    if (u + 1 >= nu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if ((u + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (u + 2 < nu) issue(u + 2);
+    const int G = u / 3, kh = u - 3 * G;
+    const char* hb = hsm + (G & 1) * HL_HALO_B;
+    const char* wb = wsm + (u % 3) * HL_WUNIT_B;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      bf16x8 wf[6], xf[2][2];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        wf[a] = *reinterpret_cast<const bf16x8*>(wb + (kw * 96 + 16 * a + fr) * 64 + ((fg ^ wswz) << 4));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          int j = jbase + (i + kh) * HL_HW + 16 * b + kw;
+          xf[i][b] = *reinterpret_cast<const bf16x8*>(hb + j * 64 + ((fg ^ (((j >> 3) & 1) << 1)) << 4));
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[i][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i][b], acc[i][a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  const int M = T * H * W;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m_row = (t * H + h0 + 2 * wave + i) * W + w0;
+    gemm_epilogue<EPI, false, 6, 2>(acc[i], Y, M, N, ldo, m_row, n0, fr, fg, ea);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // RMS_norm (+ SiLU) over channels, channels-last rows of C in {96, 192, 384} (wan/modules/vae.py:39-55, 193-197):
 //   n = bf16(||x||_2); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = bf16(silu(y))
 // (the reference's bf16 rounding points).  G lanes per pixel (16 / 32 / 64), 8 channels per lane.
@@ -309,6 +458,9 @@ __global__ __launch_bounds__(256) void cl_to_tchw_clamp_kernel(const bf16* __res
 }
 
 // ===============================================================================================================
+static int g_conv_halo = 1;       // tuning key conv_halo: 0 = always the implicit-GEMM kernel
+void ll_set_conv_halo_internal(int v) { g_conv_halo = v; }
+
 extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
                           ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample,
                           int ldo, ll_stream stream) {
@@ -333,6 +485,26 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
   g.T = T; g.H = H; g.W = W; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.KT = KT; g.KH = KH; g.up = upsample;
   g.cpt = Cin / 8; g.nchunks = nchunks; g.taps = taps; g.inv_cpt = (65536u + g.cpt - 1) / g.cpt;
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (g_conv_halo && KT == 3 && KH == 3 && !upsample && Cin % 32 == 0 && Cout % 96 == 0 && H % HL_TH == 0 && W % HL_TW == 0) {
+    static bool hattr = false;
+    if (!hattr) {
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<LL_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS);
+      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<LL_EPI_BIAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS);
+      hattr = true;
+    }
+    const int tiles_w = W / HL_TW, tiles_h = H / HL_TH, ntn_h = Cout / 96;
+    const long long nwg = (long long)T * tiles_h * tiles_w * ntn_h;
+    LL_REQUIRE(nwg < (1ll << 31), "ll_conv_cl: too many tiles");
+    dim3 hgrid((unsigned)nwg), hblock(512);
+    if (res)
+      hipLaunchKernelGGL((conv_halo_kernel<LL_EPI_BIAS_RES>), hgrid, hblock, HL_LDS, s, (const char*)x, (const char*)zero16,
+                         (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo, tiles_w, tiles_h, ntn_h, ea);
+    else
+      hipLaunchKernelGGL((conv_halo_kernel<LL_EPI_BIAS>), hgrid, hblock, HL_LDS, s, (const char*)x, (const char*)zero16,
+                         (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo, tiles_w, tiles_h, ntn_h, ea);
+    return ll_check_launch("ll_conv_cl(halo)");
+  }
   const int nk = Kpad / 64;
   const bool nt3 = (Cout % 96 == 0) && (Cout % 128 != 0), nt1 = Cout <= 32;
   const int bn = nt1 ? 32 : nt3 ? 96 : 128;
@@ -340,7 +512,6 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
   int ntm = (M + CV_BM - 1) / CV_BM, ntn = (Cout + bn - 1) / bn;
   dim3 grid(ntm * ntn), block(512);
   size_t lds = 3 * CV_STAGE;
-  hipStream_t s = (hipStream_t)stream;
 #define CV_LAUNCH(E, NTV, MD)                                                                                          \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \

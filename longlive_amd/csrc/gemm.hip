@@ -495,6 +495,7 @@ void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
 void ll_set_attn_sk_internal(int v);
 void ll_set_attn_pp_min_internal(int v);
+void ll_set_conv_halo_internal(int v);
 extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return LL_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return LL_OK; }
@@ -507,6 +508,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_pp_min_keys")) { ll_set_attn_pp_min_internal(value); return LL_OK; }
+  if (!strcmp(key, "conv_halo")) { ll_set_conv_halo_internal(value); return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }

@@ -39,6 +39,9 @@ def to_cl(x):       # [1, C, T, H, W] -> [T, H, W, C]
     (1, 16, 24, 96, 3, 3, 3, False, False),      # head: Cout 3 -> padded to 8, NT = 1 tile
     (1, 4, 4, 16, 16, 1, 1, False, False),       # conv2: K = 16 -> one padded k-step
     (2, 40, 50, 96, 96, 3, 3, False, False),     # several tiles per XCD
+    (2, 32, 64, 96, 96, 3, 3, False, True),      # H % 16 == 0, W % 32 == 0: the halo-tile kernel, 2 x 2 tiles per frame, residual
+    (1, 16, 32, 192, 192, 3, 3, False, False),   # halo kernel: one tile (all four borders), six channel slices, two N tiles
+    (3, 48, 96, 96, 96, 3, 3, False, False),     # halo kernel: interior tiles, three frames
 ])
 def test_conv_cl(ops, T, H, W, Cin, Cout, KT, KH, up, with_res):
     x = hn("cx", (1, Cin, T, H, W))
@@ -64,6 +67,24 @@ def test_conv_cl(ops, T, H, W, Cin, Cout, KT, KH, up, with_res):
     assert got.shape[-1] == geo[1]
     # fp32 accumulation in a different order than the CPU conv: <= 1 ulp apart nearly everywhere
     assert_bf16_close(got[..., :Cout], to_cl(want), 2, 0.97, f"conv_cl {Cin}->{Cout} k{KT}x{KH}x{KH} up={up}")
+
+
+def test_conv_halo_and_implicit_gemm_kernels_agree(ops):
+    """Same convolution through both kernels (tuning key conv_halo): fp32 sums in a different K order, <= 1 bf16 ulp apart."""
+    from longlive_amd import _lib
+    T, H, W, C = 2, 32, 64, 96
+    x = hn("hx", (1, C, T + 2, H, W))
+    w = hn("hw", (C, C, 3, 3, 3), 1.0 / math.sqrt(C * 27))
+    pk, pb, geo = ops.pack_conv_weight(w.to(DEV), hn("hb", (C,), 0.1).to(DEV))
+    outs = []
+    try:
+        for v in (1, 0):
+            assert _lib.load().ll_set_tuning(b"conv_halo", v) == 0
+            outs.append(ops.conv_cl(to_cl(x).to(DEV), pk, pb, geo))
+    finally:
+        _lib.load().ll_set_tuning(b"conv_halo", 1)
+    torch.cuda.synchronize()
+    assert_bf16_close(outs[0], outs[1], 1, 0.9, "halo vs implicit GEMM")
 
 
 def test_conv_cl_rejects_bad_shapes(ops):
