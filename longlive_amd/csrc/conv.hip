@@ -226,21 +226,38 @@ __global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* 
 //   another order (parity bar unchanged: <= 2 bf16 ulp against fp32 conv3d).
 #define HL_TH 16
 #define HL_TW 32
-#define HL_HW (HL_TW + 2)
-#define HL_HALO_PX ((HL_TH + 2) * HL_HW)            // 612
-#define HL_HALO_PIECES ((HL_HALO_PX + 15) / 16)     // 39 (16 rows of 64 B per 1-KiB LDS-DMA piece)
-#define HL_HALO_B (HL_HALO_PIECES * 1024)
-#define HL_WUNIT_B (18 * 1024)                      // 3 kw x 96 co x 64 B
-#define HL_LDS (2 * HL_HALO_B + 3 * HL_WUNIT_B)
+#define HL_LDS(NCB, UP) (2 * hl_halo_pieces(UP) * 1024 + 3 * 3 * (NCB) * 1024)
 
-template <int EPI>
+// UP = 0: 3x3x3 causal convolution, halo (16+2) x (32+2) of input frame t - 2 + kt.
+// UP = 1: Conv2d 3x3 on the nearest x2 upsampled frame (Resample, vae.py:74-84): output pixel (h, w), tap (kh, kw) reads source
+//         pixel ((h + kh - 1) >> 1, (w + kw - 1) >> 1); the halo is the (8+2) x (16+2) SOURCE region of the tile (h0, w0 even),
+//         a fragment's 16 rows are per-lane halo rows (two output pixels share a source pixel).
+__host__ __device__ constexpr int hl_halo_w(int up) { return up ? HL_TW / 2 + 2 : HL_TW + 2; }
+__host__ __device__ constexpr int hl_halo_px(int up) { return (up ? HL_TH / 2 + 2 : HL_TH + 2) * hl_halo_w(up); }   // 612 / 180
+__host__ __device__ constexpr int hl_halo_pieces(int up) { return (hl_halo_px(up) + 15) / 16; }                      // 39 / 12
+
+template <int N>
+__device__ __forceinline__ void hl_wait_vm() {
+  static_assert(N == 1 || N == 3 || N == 5 || N == 6 || N == 8, "add the literal");
+  if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+// NCB = 16-channel output blocks per workgroup: 6 (96 channels) or 1 (the 3-channel head, weights padded to 8 rows).
+template <int EPI, int NCB, int UP>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restrict__ x, const char* __restrict__ zero,
                                                            const char* __restrict__ Wt, bf16* __restrict__ Y, int T, int H,
                                                            int W, int Cin, int N, size_t wrow_bytes, int ldo, int tiles_w,
                                                            int tiles_h, int ntn, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HW_ = hl_halo_w(UP), HPX = hl_halo_px(UP), HPIECES = hl_halo_pieces(UP);
+  constexpr int HALO_B = HPIECES * 1024, WPIECES = 3 * NCB, WUNIT_B = WPIECES * 1024;
+  constexpr int NH = (HPIECES + 7) / 8, NWP = (WPIECES + 7) / 8;      // pieces per wave: halo 5 / 2, weights 3 / 1
   char* const hsm = smem;
-  char* const wsm = smem + 2 * HL_HALO_B;
+  char* const wsm = smem + 2 * HALO_B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
@@ -250,111 +267,119 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
   const int tw = tile % tiles_w;
   tile /= tiles_w;
   const int th = tile % tiles_h, t = tile / tiles_h;
-  const int h0 = th * HL_TH, w0 = tw * HL_TW, n0 = nt * 96;
+  const int h0 = th * HL_TH, w0 = tw * HL_TW, n0 = nt * (16 * NCB);
+  const int Wo = UP ? 2 * W : W, Ho = UP ? 2 * H : H;
   const long long fb = (long long)H * W * Cin * 2;
-  const int nslice = Cin >> 5, nu = 9 * nslice;
+  const int nslice = Cin >> 5, nu = (UP ? 3 : 9) * nslice;
 
-  // ---- staging plan (loop invariant per lane): 5 halo pieces and 3 weight pieces per wave and unit; a wave without a fifth /
-  // third piece of its own re-issues its previous one (same bytes to the same place) so that every wave's vmcnt counts agree
-  int hoff[5];            // byte offset of the lane's 16-byte part inside frame (t - 2), channel slice 0; < 0: zero row
-  int hdst[5];
+  // ---- staging plan (loop invariant per lane).  Every wave issues NWP weight pieces per unit and NH halo pieces per group;
+  // a wave whose index runs past the last piece wraps around (same bytes to the same place) so that all vmcnt counts agree.
+  int hoff[NH];           // byte offset of the lane's 16-byte part inside the source frame, channel slice 0; < 0: zero row
+  int hdst[NH];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    int p = wave + 8 * k;
-    p = p < HL_HALO_PIECES ? p : p - 8;
+  for (int k = 0; k < NH; ++k) {
+    int p = (wave + 8 * k) % HPIECES;
     int j = 16 * p + (lane >> 2);
-    int hr = j / HL_HW, hc = j - hr * HL_HW;
-    int hy = h0 - 1 + hr, wx = w0 - 1 + hc;
-    bool ok = j < HL_HALO_PX && hy >= 0 && hy < H && wx >= 0 && wx < W;
+    int hr = j / HW_, hc = j - hr * HW_;
+    int hy = (UP ? (h0 >> 1) : h0) - 1 + hr, wx = (UP ? (w0 >> 1) : w0) - 1 + hc;
+    bool ok = j < HPX && hy >= 0 && hy < H && wx >= 0 && wx < W;
     int part = (lane & 3) ^ (((j >> 3) & 1) << 1);
     hoff[k] = ok ? (hy * W + wx) * Cin * 2 + part * 16 : -1;
     hdst[k] = p * 1024;
   }
-  const char* wsrc[3];
-  int wdst[3];
+  const char* wsrc[NWP];
+  int wdst[NWP];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    int bpc = wave + 8 * k;
-    bpc = bpc < 18 ? bpc : bpc - 8;
-    int kw = bpc / 6, pp = bpc - 6 * kw;
+  for (int k = 0; k < NWP; ++k) {
+    int bpc = (wave + 8 * k) % WPIECES;
+    int kw = bpc / NCB, pp = bpc - NCB * kw;
     int row = 16 * pp + (lane >> 2);
     int part = (lane & 3) ^ (((row >> 3) & 1) << 1);
-    wsrc[k] = Wt + (size_t)(n0 + row) * wrow_bytes + (size_t)kw * Cin * 2 + part * 16;
+    int nrow = n0 + row;
+    nrow = nrow < N ? nrow : N - 1;                          // head: 8 weight rows feed a 16-row block (rows >= N are not stored)
+    wsrc[k] = Wt + (size_t)nrow * wrow_bytes + (size_t)kw * Cin * 2 + part * 16;
     wdst[k] = bpc * 1024;
   }
-  const char* xt = x + (long long)(t - 2) * fb;
+  const char* xt = x + (long long)(UP ? t : t - 2) * fb;
   auto issue = [&](int u) {
     int G = u / 3, kh = u - 3 * G;
-    int kt = G / nslice, sl = G - kt * nslice;
-    char* wb = wsm + (u % 3) * HL_WUNIT_B;
+    int kt = UP ? 0 : G / nslice, sl = G - kt * nslice;
+    char* wb = wsm + (u % 3) * WUNIT_B;
     unsigned woff = (unsigned)(((kt * 9 + kh * 3) * Cin + sl * 32) * 2);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < NWP; ++k)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[k] + woff), (lptr_t)(wb + wdst[k]), 16, 0, 0);
     if (kh == 0) {
-      char* hb = hsm + (G & 1) * HL_HALO_B;
+      char* hb = hsm + (G & 1) * HALO_B;
       const char* xf = xt + (long long)kt * fb + sl * 64;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) {
+      for (int k = 0; k < NH; ++k) {
         const char* src = hoff[k] >= 0 ? xf + hoff[k] : zero;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(hb + hdst[k]), 16, 0, 0);
       }
     }
   };
 
-  f32x4 acc[2][6][2];
+  f32x4 acc[2][NCB][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < NCB; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[i][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // per-lane fragment row indices: halo row j = (2 wave + i + kh) * 34 + 16 b + kw + fr; weight row = kw * 96 + 16 a + fr
-  const int jbase = (2 * wave) * HL_HW + fr;
+  // fragment rows.  UP = 0: halo row j = (2 wave + i + kh) * 34 + 16 b + kw + fr.  UP = 1: j = (((2 wave + i + kh - 1) >> 1) + 1) * 18
+  // + ((16 b + fr + kw - 1) >> 1) + 1.  Weight row = kw * 16 NCB + 16 a + fr.
+  const int jbase = (2 * wave) * HW_ + fr;
   const int wswz = ((fr >> 3) & 1) << 1;
 
   issue(0);
   if (nu > 1) issue(1);
   for (int u = 0; u < nu; ++u) {
-    // unit u has landed; unit u + 1's pieces (3 weight, + 5 halo when it opens a group) may stay in flight
+    // unit u has landed; unit u + 1's pieces (NWP weight, + NH halo when it opens a group) may stay in flight
     if (u + 1 >= nu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if ((u + 1) % 3 == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if ((u + 1) % 3 == 0) hl_wait_vm<NWP + NH>();
+    else hl_wait_vm<NWP>();
     __builtin_amdgcn_s_barrier();
     if (u + 2 < nu) issue(u + 2);
     const int G = u / 3, kh = u - 3 * G;
-    const char* hb = hsm + (G & 1) * HL_HALO_B;
-    const char* wb = wsm + (u % 3) * HL_WUNIT_B;
+    const char* hb = hsm + (G & 1) * HALO_B;
+    const char* wb = wsm + (u % 3) * WUNIT_B;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      bf16x8 wf[6], xf[2][2];
+      bf16x8 wf[NCB], xf[2][2];
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
-        wf[a] = *reinterpret_cast<const bf16x8*>(wb + (kw * 96 + 16 * a + fr) * 64 + ((fg ^ wswz) << 4));
+      for (int a = 0; a < NCB; ++a)
+        wf[a] = *reinterpret_cast<const bf16x8*>(wb + (kw * (16 * NCB) + 16 * a + fr) * 64 + ((fg ^ wswz) << 4));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          int j = jbase + (i + kh) * HL_HW + 16 * b + kw;
+          int j;
+          if (UP) j = (((2 * wave + i + kh - 1) >> 1) + 1) * HW_ + ((16 * b + fr + kw - 1) >> 1) + 1;
+          else j = jbase + (i + kh) * HW_ + 16 * b + kw;
           xf[i][b] = *reinterpret_cast<const bf16x8*>(hb + j * 64 + ((fg ^ (((j >> 3) & 1) << 1)) << 4));
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int a = 0; a < NCB; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
             acc[i][a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[i][b], acc[i][a][b], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  const int M = T * H * W;
+  // Partial tiles at the right / bottom edge: the halo reads outside the image were zero rows; here an image row below the frame
+  // is skipped (wave-uniform) and the row limit handed to the epilogue is the END OF THIS IMAGE ROW, so pixels right of the
+  // frame fail its m < M test (their loads are clamped to the row's last pixel).
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int m_row = (t * H + h0 + 2 * wave + i) * W + w0;
-    gemm_epilogue<EPI, false, 6, 2>(acc[i], Y, M, N, ldo, m_row, n0, fr, fg, ea);
+    int hrow = h0 + 2 * wave + i;
+    if (hrow >= Ho) continue;
+    int m_row = (t * Ho + hrow) * Wo + w0;
+    gemm_epilogue<EPI, false, NCB, 2>(acc[i], Y, (t * Ho + hrow + 1) * Wo, N, ldo, m_row, n0, fr, fg, ea);
   }
 }
 
@@ -486,24 +511,40 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
   g.cpt = Cin / 8; g.nchunks = nchunks; g.taps = taps; g.inv_cpt = (65536u + g.cpt - 1) / g.cpt;
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
   hipStream_t s = (hipStream_t)stream;
-  if (g_conv_halo && KT == 3 && KH == 3 && !upsample && Cin % 32 == 0 && Cout % 96 == 0 && H % HL_TH == 0 && W % HL_TW == 0) {
-    static bool hattr = false;
-    if (!hattr) {
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<LL_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS);
-      (void)hipFuncSetAttribute((const void*)conv_halo_kernel<LL_EPI_BIAS_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HL_LDS);
-      hattr = true;
+  {
+    // halo-tile kernel: 3x3x3 (96-channel tiles, or the <= 16-channel head) and the upsampled 1x3x3 (96-channel tiles)
+    const bool shape3 = KT == 3 && KH == 3 && !upsample, shape_up = KT == 1 && KH == 3 && upsample == 1;
+    const bool head = shape3 && Cout <= 16, wide = Cout % 96 == 0;
+    // partial edge tiles are allowed when they waste < 30 % of the tile grid (60 x 104: 4 x 4 tiles, 24 %)
+    const int tiles_w = (Wo + HL_TW - 1) / HL_TW, tiles_h = (Ho + HL_TH - 1) / HL_TH;
+    const bool fits = (long long)Ho * Wo * 10 >= 7ll * tiles_w * HL_TW * tiles_h * HL_TH && Wo % 2 == 0 && Ho % 2 == 0;
+    if (g_conv_halo && (shape3 || shape_up) && (wide || head) && Cin % 32 == 0 && fits) {
+      const int ntn_h = head ? 1 : Cout / 96;
+      const long long nwg = (long long)T * tiles_h * tiles_w * ntn_h;
+      LL_REQUIRE(nwg < (1ll << 31), "ll_conv_cl: too many tiles");
+      dim3 hgrid((unsigned)nwg), hblock(512);
+#define HL_LAUNCH(E, NCBV, UPV)                                                                                        \
+      do {                                                                                                             \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+          (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, NCBV, UPV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)HL_LDS(NCBV, UPV));                                                           \
+          attr = true;                                                                                                 \
+        }                                                                                                              \
+        hipLaunchKernelGGL((conv_halo_kernel<E, NCBV, UPV>), hgrid, hblock, HL_LDS(NCBV, UPV), s, (const char*)x,      \
+                           (const char*)zero16, (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo,  \
+                           tiles_w, tiles_h, ntn_h, ea);                                                               \
+      } while (0)
+      if (shape_up) {
+        if (res) HL_LAUNCH(LL_EPI_BIAS_RES, 6, 1); else HL_LAUNCH(LL_EPI_BIAS, 6, 1);
+      } else if (head) {
+        if (res) HL_LAUNCH(LL_EPI_BIAS_RES, 1, 0); else HL_LAUNCH(LL_EPI_BIAS, 1, 0);
+      } else {
+        if (res) HL_LAUNCH(LL_EPI_BIAS_RES, 6, 0); else HL_LAUNCH(LL_EPI_BIAS, 6, 0);
+      }
+#undef HL_LAUNCH
+      return ll_check_launch("ll_conv_cl(halo)");
     }
-    const int tiles_w = W / HL_TW, tiles_h = H / HL_TH, ntn_h = Cout / 96;
-    const long long nwg = (long long)T * tiles_h * tiles_w * ntn_h;
-    LL_REQUIRE(nwg < (1ll << 31), "ll_conv_cl: too many tiles");
-    dim3 hgrid((unsigned)nwg), hblock(512);
-    if (res)
-      hipLaunchKernelGGL((conv_halo_kernel<LL_EPI_BIAS_RES>), hgrid, hblock, HL_LDS, s, (const char*)x, (const char*)zero16,
-                         (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo, tiles_w, tiles_h, ntn_h, ea);
-    else
-      hipLaunchKernelGGL((conv_halo_kernel<LL_EPI_BIAS>), hgrid, hblock, HL_LDS, s, (const char*)x, (const char*)zero16,
-                         (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo, tiles_w, tiles_h, ntn_h, ea);
-    return ll_check_launch("ll_conv_cl(halo)");
   }
   const int nk = Kpad / 64;
   const bool nt3 = (Cout % 96 == 0) && (Cout % 128 != 0), nt1 = Cout <= 32;

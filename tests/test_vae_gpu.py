@@ -42,6 +42,12 @@ def to_cl(x):       # [1, C, T, H, W] -> [T, H, W, C]
     (2, 32, 64, 96, 96, 3, 3, False, True),      # H % 16 == 0, W % 32 == 0: the halo-tile kernel, 2 x 2 tiles per frame, residual
     (1, 16, 32, 192, 192, 3, 3, False, False),   # halo kernel: one tile (all four borders), six channel slices, two N tiles
     (3, 48, 96, 96, 96, 3, 3, False, False),     # halo kernel: interior tiles, three frames
+    (2, 32, 32, 96, 3, 3, 3, False, False),      # halo kernel, head: one 16-channel block fed by the 8 padded weight rows
+    (2, 8, 16, 384, 192, 1, 3, True, False),     # halo kernel, upsampled 1x3x3: one output tile (16 x 32), twelve slices
+    (1, 24, 48, 192, 96, 1, 3, True, False),     # halo kernel, upsampled: 3 x 3 output tiles
+    (2, 30, 52, 384, 384, 3, 3, False, False),   # halo kernel, partial tiles at the right and bottom edge (60 x 104 in small), 4 N tiles
+    (1, 30, 52, 96, 96, 3, 3, False, True),      # ... with the fused residual
+    (1, 15, 26, 192, 96, 1, 3, True, False),     # halo kernel, upsampled, partial edge tiles (output 30 x 52)
 ])
 def test_conv_cl(ops, T, H, W, Cin, Cout, KT, KH, up, with_res):
     x = hn("cx", (1, Cin, T, H, W))
