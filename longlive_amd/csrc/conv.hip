@@ -220,7 +220,10 @@ __global__ __launch_bounds__(512, 2) void conv_cl_kernel(ConvGeo g, const char* 
 // weights in three 18-KiB units (one per kh): 94 KiB staged per 1728 MFMAs per wave pair instead of 396 KiB.
 //   LDS: 2 halo slots x 39 KiB + 3 weight-unit slots x 18 KiB = 132 KiB; unit u = ((kt * nslice) + slice) * 3 + kh, two units
 //   staged ahead, one barrier per unit (72 MFMAs per wave).  Halo / weight rows are 64 B (32 channels); 16-byte part q of row j
-//   sits at position q ^ (((j >> 3) & 1) << 1): conflict-free ds_read_b128 fragments for 16-aligned runs of 16 rows.
+//   sits at position q ^ (((j >> 2) & 1) << 1): ds_read_b128 serves lanes {fr 0-3, 12-15 | part p} with {fr 4-11 | part p ^ 1}
+//   per cycle group, i.e. for every row residue mod 4 the rows r, r + 12 at part p and r + 4, r + 8 at part p ^ 1: with the swizzle
+//   on row bit 2 those four land on four different 16-byte slots for ANY start row, so the kw-shifted fragments are conflict-free
+//   too (bit 3, the first choice, was conflict-free only for aligned runs: PMC 25 % of the LDS cycles were conflict cycles).
 //   Waves: wave w owns image rows 2w, 2w+1 of the tile (4 blocks of 16 pixels) x 6 blocks of 16 channels = 96 accumulator
 //   registers; the accumulation order over K is (kt, slice, kh, kw) instead of (tap, channel) -- same products, fp32 sums in
 //   another order (parity bar unchanged: <= 2 bf16 ulp against fp32 conv3d).
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
     int hr = j / HW_, hc = j - hr * HW_;
     int hy = (UP ? (h0 >> 1) : h0) - 1 + hr, wx = (UP ? (w0 >> 1) : w0) - 1 + hc;
     bool ok = j < HPX && hy >= 0 && hy < H && wx >= 0 && wx < W;
-    int part = (lane & 3) ^ (((j >> 3) & 1) << 1);
+    int part = (lane & 3) ^ (((j >> 2) & 1) << 1);
     hoff[k] = ok ? (hy * W + wx) * Cin * 2 + part * 16 : -1;
     hdst[k] = p * 1024;
   }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
     int bpc = (wave + 8 * k) % WPIECES;
     int kw = bpc / NCB, pp = bpc - NCB * kw;
     int row = 16 * pp + (lane >> 2);
-    int part = (lane & 3) ^ (((row >> 3) & 1) << 1);
+    int part = (lane & 3) ^ (((row >> 2) & 1) << 1);
     int nrow = n0 + row;
     nrow = nrow < N ? nrow : N - 1;                          // head: 8 weight rows feed a 16-row block (rows >= N are not stored)
     wsrc[k] = Wt + (size_t)nrow * wrow_bytes + (size_t)kw * Cin * 2 + part * 16;
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
   // fragment rows.  UP = 0: halo row j = (2 wave + i + kh) * 34 + 16 b + kw + fr.  UP = 1: j = (((2 wave + i + kh - 1) >> 1) + 1) * 18
   // + ((16 b + fr + kw - 1) >> 1) + 1.  Weight row = kw * 16 NCB + 16 a + fr.
   const int jbase = (2 * wave) * HW_ + fr;
-  const int wswz = ((fr >> 3) & 1) << 1;
+  const int wswz = ((fr >> 2) & 1) << 1;
 
   issue(0);
   if (nu > 1) issue(1);
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
           int j;
           if (UP) j = (((2 * wave + i + kh - 1) >> 1) + 1) * HW_ + ((16 * b + fr + kw - 1) >> 1) + 1;
           else j = jbase + (i + kh) * HW_ + 16 * b + kw;
-          xf[i][b] = *reinterpret_cast<const bf16x8*>(hb + j * 64 + ((fg ^ (((j >> 3) & 1) << 1)) << 4));
+          xf[i][b] = *reinterpret_cast<const bf16x8*>(hb + j * 64 + ((fg ^ (((j >> 2) & 1) << 1)) << 4));
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
