@@ -315,6 +315,7 @@ def run(mode: str, config, synthetic: bool = False, device: Optional[torch.devic
     interactive = mode == "interactive"
     cls = InteractiveCausalInferencePipeline if interactive else CausalInferencePipeline
     pipeline = cls(config, device, generator=gen, text_encoder=enc, vae=vae)
+    pipeline.overlap_decode = bool(config.get("overlap_decode", True))     # blocks are decoded while the next ones are generated (same video)
     if interactive:
         switch = parse_switch_frame_indices(config.switch_frame_indices)
         dataset = MultiTextDataset(config.data_path)

@@ -60,6 +60,7 @@ class CausalInferencePipeline(nn.Module):
         # Opt-in (+0.65 % frames/s measured): off by default so that per-kernel timings and the bench's roofline figure describe
         # kernels running alone on the device.
         self.overlap_context = False
+        self.overlap_decode = False      # inference(): decode each block on a second stream while the next one is generated (same video, bit for bit)
         self._aux = None
         self._ctx_events = None
         self._ctx_pending = False
@@ -123,6 +124,11 @@ class CausalInferencePipeline(nn.Module):
         self.generator(noisy_image_or_video=denoised, conditional_dict=cond, timestep=ctx_t, kv_cache=self.kv_cache1,
                        crossattn_cache=self.crossattn_cache, current_start=start_frame * self.frame_seq_length,
                        **self._kv_only_kw())
+
+    def _side_decoder(self, noise: torch.Tensor):
+        if self.overlap_decode and self.vae is not None and noise.is_cuda and noise.shape[0] == 1:
+            return _SideDecoder(self.vae)
+        return None
 
     def _use_overlap(self, t: torch.Tensor) -> bool:
         return (self.overlap_context and t.is_cuda and getattr(self.generator, "supports_layer_events", False)
@@ -231,19 +237,24 @@ class CausalInferencePipeline(nn.Module):
         prof.stop("init")
         prof.start("diffusion")
         start = 0
+        side = self._side_decoder(noise)
         for _ in range(num_blocks):
             nf = self.num_frame_per_block
             prof.block_start()
             denoised = self._denoise_block(noise[:, start:start + nf], cond, start, batch_size, nf)
             output[:, start:start + nf] = denoised
             self._clean_context_pass(denoised, cond, start)
+            if side is not None:
+                side.push(denoised)
             prof.block_end()
             start += nf
         self._join_context()
         prof.stop("diffusion")
         prof.start("vae")
         video = None
-        if self.vae is not None:
+        if side is not None:
+            video = side.finish()
+        elif self.vae is not None:
             video = self.vae.decode_to_pixel(output, use_cache=False)
             video = (video * 0.5 + 0.5).clamp(0, 1)
         prof.stop("vae")
@@ -288,6 +299,36 @@ def _mk(args, name, default):
     if isinstance(mk, dict):
         return mk.get(name, default)
     return getattr(mk, name, default)
+
+
+class _SideDecoder:
+    """inference() with overlap_decode: every finished block goes through the VAE's streaming decode on a second HIP stream while
+    the next block is generated; the pieces concatenated equal the one-shot decode of the finished latents bit for bit
+    (tests/test_vae_gpu.py).  Batch 1 only (the streaming cache holds one stream)."""
+
+    def __init__(self, vae):
+        self.vae, self.pieces, self.side = vae, [], None
+        vae.model.clear_cache()
+
+    def push(self, latents: torch.Tensor):
+        main = torch.cuda.current_stream(latents.device)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=latents.device)
+        self.side.wait_stream(main)
+        latents.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            v = self.vae.decode_to_pixel(latents, use_cache=True)
+            self.pieces.append((v * 0.5 + 0.5).clamp(0, 1))
+
+    def finish(self) -> torch.Tensor:
+        main = torch.cuda.current_stream(self.side.device)
+        main.wait_stream(self.side)
+        for p in self.pieces:
+            p.record_stream(main)
+        video = torch.cat(self.pieces, 1)
+        self.pieces = []
+        self.vae.model.clear_cache()
+        return video
 
 
 class _Profiler:

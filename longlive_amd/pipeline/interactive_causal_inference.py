@@ -66,6 +66,7 @@ class InteractiveCausalInferencePipeline(CausalInferencePipeline):
         prof.start("diffusion")
         seg, start, switch_blocks = 0, 0, []
         next_switch = switch_frame_indices[0] if switch_frame_indices else None
+        side = self._side_decoder(noise)
         for blk in range(num_blocks):
             nf = self.num_frame_per_block
             prof.block_start()
@@ -78,13 +79,17 @@ class InteractiveCausalInferencePipeline(CausalInferencePipeline):
             denoised = self._denoise_block(noise[:, start:start + nf], cond, start, batch_size, nf)
             output[:, start:start + nf] = denoised
             self._clean_context_pass(denoised, cond, start)
+            if side is not None:
+                side.push(denoised)
             prof.block_end()
             start += nf
         self._join_context()
         prof.stop("diffusion")
         prof.start("vae")
         video = None
-        if self.vae is not None:
+        if side is not None:
+            video = side.finish()
+        elif self.vae is not None:
             video = self.vae.decode_to_pixel(output, use_cache=False)
             video = (video * 0.5 + 0.5).clamp(0, 1)
         prof.stop("vae")

@@ -210,6 +210,13 @@ def test_pipeline_streams_pixels_identical_to_one_shot_decode(vae):
     pieces = [px for _, px in P.stream_video(noise, ["p0"])]
     assert [p.shape[1] for p in pieces] == [9, 12, 12]
     assert torch.equal(torch.cat(pieces, 1), video)
+    # inference() with the per-block side-stream decode: the same video
+    P.randn_like = TM.TD.HashRandn(43)
+    P.overlap_decode = True
+    video2, lat2 = P.inference(noise, ["p0"], return_latents=True)
+    P.overlap_decode = False
+    torch.cuda.synchronize()
+    assert torch.equal(video2, video) and torch.equal(lat2, lat)
     # decode on a second stream beside the next block's generation: same frames, same order, one block later
     P.randn_like = TM.TD.HashRandn(43)
     got = [(st, px) for st, px in P.stream_video(noise, ["p0"], overlap_decode=True)]
