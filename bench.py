@@ -385,6 +385,8 @@ def run_replica(args, rank, world, local_rank, sync):
     del sd
     quant = None if args.quant == "none" else args.quant
     gen.model.set_quant(quant)
+    if os.environ.get("LL_SPLITK") is not None:                        # kernel A/B only
+        gen.model.ffn2_splitk = os.environ["LL_SPLITK"] == "1"
     if os.environ.get("LL_MODTAB") == "0":                             # kernel A/B only
         gen.model.use_modulation_table = False
     if os.environ.get("LL_FUSE_V") == "0":

@@ -30,6 +30,9 @@ SIGNATURES = {
     "ll_qk_norm_rope_kv_store": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_kv_roll": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_gemm_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "ll_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
+    "ll_gemm_splitk_workspace_bytes": [_i, _i],
+    "ll_gemm_splitk_plan": [_i, _i, _i],
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ll_gemm_bf16_qkv": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_gemm_w8a8_qkv": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -51,7 +54,8 @@ SIGNATURES = {
     "ll_gather_rows": [_p, _p, _p, _i, _i, _ll, _p],
     "ll_t5_attention": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
-_RESTYPES = {"ll_last_error": C.c_char_p, "ll_flash_attn_workspace_bytes": C.c_longlong}
+_RESTYPES = {"ll_last_error": C.c_char_p, "ll_flash_attn_workspace_bytes": C.c_longlong,
+             "ll_gemm_splitk_workspace_bytes": C.c_longlong}
 
 _lib = None
 

@@ -477,6 +477,148 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   gemm_epilogue<EPI, I8, 4, 8>(acc, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, fr, fg, ea);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// v4sk: the 256 x 256 ping-pong tile with K cut in two (split-K 2) for N = 1536-wide GEMMs with a long K (FFN2:
+// 4680 x 1536 x 8960).  256 x 128 tiles are forced there by the tile count (19 x 12 = 228 workgroups = one round); they stage
+// (256 + 128) x 128 B per K-step against 1024 MFMA cycles, and the LDS-DMA path is what bounds the K-loop.  The
+// two K-halves of a 256 x 256 tile are 2 x 114 = 228 workgroups again, each staging 512 x 128 B per 2048 MFMA cycles: 33 % fewer
+// staged bytes per FLOP.  The halves meet in the epilogue: workgroup `split` keeps the rows of its waves' MH = split half
+// (64 of every 128), hands the fp32 accumulators of the other half to its partner through a workspace in MFMA register layout
+// (128 KiB per workgroup, whole 128-byte lines per store instruction), waits for the partner's half, adds, and runs the usual
+// fused epilogue on the half it owns -- each workgroup finishes half a tile, nobody idles.
+//   Hand-off (MI355X_MICROARCH.md, hand-offs without an agent release): every partial store and load is `sc1`; each storing wave
+//   runs s_waitcnt vmcnt(0), then a workgroup barrier, then ONE lane's agent-scope atomic add on the workgroup's flag; the
+//   consumer's one lane polls the partner's flag with an sc1 load, resets it for the next launch, and a workgroup barrier stands
+//   between that poll and every load of the bytes.  Both workgroups of a pair must be resident (each waits for the other):
+//   the launcher only takes this path when the whole grid fits the device in one round (one workgroup per CU: 128 KiB LDS).
+//   Pairs are placed on ONE XCD (block b -> XCD b % 8: pair = (b / 8) / 2), so the hand-off stays in that XCD's L2 / its memory
+//   channel neighbourhood; correctness does not depend on that placement.
+// fp32 addition commutes: the result does not depend on which half arrives first (deterministic), but it differs in the last
+// bits from the unsplit kernels' single accumulation chain.
+#define V4SK_PART_FLOATS (8 * 16 * 64 * 4)      // per (tile, split): [wave][a][b'][lane][4]
+#define V4SK_FLAG_BYTES 4096
+
+__device__ __forceinline__ void sk_store_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int EPI, int SPLIT>
+__device__ __forceinline__ void v4sk_finish(f32x4 (&acc)[4][8], float* __restrict__ part, unsigned* __restrict__ flags, int tile,
+                                            bf16* __restrict__ Y, int M, int N, int ldo, int mw, int nw, int wave, int lane,
+                                            const EpiArgs& ea) {
+  constexpr int GIVE = SPLIT ^ 1;
+  float* mine = part + ((size_t)tile * 2 + SPLIT) * V4SK_PART_FLOATS + ((size_t)wave * 16 * 64 + lane) * 4;
+  float* theirs = part + ((size_t)tile * 2 + GIVE) * V4SK_PART_FLOATS + ((size_t)wave * 16 * 64 + lane) * 4;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sk_store_sc1(mine + (a * 4 + b) * 256, acc[a][GIVE * 4 + b]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(flags + tile * 2 + SPLIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* pf = flags + tile * 2 + GIVE;
+    unsigned v;
+    do {
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pf) : "memory");
+      if (v == 0) __builtin_amdgcn_s_sleep(4);
+    } while (v == 0);
+    __hip_atomic_store(pf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this workspace
+  }
+  __syncthreads();
+  f32x4 hlo[4][2], hhi[4][2];     // two 32-row halves: the gate-residual epilogue of a 64-row batch does not fit the register file
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float* q = theirs + a * 4 * 256;
+    f32x4 r0, r1, r2, r3;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(q)
+        : "memory");
+    hlo[a][0] = acc[a][SPLIT * 4 + 0] + r0;
+    hlo[a][1] = acc[a][SPLIT * 4 + 1] + r1;
+    hhi[a][0] = acc[a][SPLIT * 4 + 2] + r2;
+    hhi[a][1] = acc[a][SPLIT * 4 + 3] + r3;
+  }
+  gemm_epilogue<EPI, false, 4, 2>(hlo, Y, M, N, ldo, mw + SPLIT * 64, nw, lane & 15, lane >> 4, ea);
+  gemm_epilogue<EPI, false, 4, 2>(hhi, Y, M, N, ldo, mw + SPLIT * 64 + 32, nw, lane & 15, lane >> 4, ea);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restrict__ X, const char* __restrict__ Wt,
+                                                           bf16* __restrict__ Y, int M, int N, int nkh, size_t xrow_bytes,
+                                                           size_t wrow_bytes, int ldo, int ntiles, int ntn,
+                                                           float* __restrict__ part, unsigned* __restrict__ flags, EpiArgs ea) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool I8 = false;
+  typedef typename Ty<I8>::frag frag_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // block b runs on XCD b % 8: both halves of a tile on one XCD, every XCD a contiguous range of tiles
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int pair = idx >> 1, split = idx & 1;
+  const int q_ = ntiles >> 3, r_ = ntiles & 7;
+  const int cnt = q_ + (xcd < r_ ? 1 : 0), start = xcd * q_ + (xcd < r_ ? xcd : r_);
+  if (pair >= cnt) return;                                  // grid padding (whole workgroup, before any barrier)
+  const int tile = start + pair;
+  const int mt_ = tile / ntn, nt_ = tile - mt_ * ntn;
+  const int m0 = mt_ * V3_BM, n0 = nt_ * V3_BN;
+  const int k0 = split * nkh;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = acc_zero<I8>();
+
+  const int xi = (wave < 4 ? 2 * wave : 16 + 2 * (wave - 4));
+  const int yi = (wave >> 1) * 8 + (wave & 1) * 2;
+  auto stage_x = [&](int kt, int half) {
+    int kc = (kt < nkh ? kt : nkh - 1) + k0;
+    stage_rows(X, xrow_bytes, m0, M, kc * ROWB, smem + (kt & 1) * V3_STAGE, xi + half * 8, 2, lane);
+  };
+  auto stage_y = [&](int kt, int half) {
+    int kc = (kt < nkh ? kt : nkh - 1) + k0;
+    stage_rows(Wt, wrow_bytes, n0, N, kc * ROWB, smem + (kt & 1) * V3_STAGE + V3_BM * ROWB, yi + half * 4, 2, lane);
+  };
+  stage_x(0, 0); stage_y(0, 1); stage_x(0, 1); stage_y(0, 0);
+  stage_x(1, 0); stage_y(1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  frag_t xf[4][2], wf[2][2];
+  for (int kt = 0; kt < nkh; ++kt) {
+    const char* xs = smem + (kt & 1) * V3_STAGE;
+    const char* ws = xs + V3_BM * ROWB;
+    V4_LOAD_B(0);
+    V4_LOAD_A(0);
+    stage_x(kt + 1, 1);
+    V4_MMA(0, 0);
+    V4_LOAD_B(1);
+    stage_y(kt + 1, 0);
+    V4_MMA(0, 1);
+    V4_LOAD_A(1);
+    stage_x(kt + 2, 0);
+    V4_MMA(1, 1);
+    V4_LOAD_B(0);
+    stage_y(kt + 2, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    V4_MMA(1, 0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (split == 0) v4sk_finish<EPI, 0>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+  else v4sk_finish<EPI, 1>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+}
 #undef V4_LOAD_A
 #undef V4_LOAD_B
 #undef V4_MMA
@@ -750,6 +892,78 @@ extern "C" int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b
              rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
   launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream);
   return ll_check_launch("ll_gemm_bf16");
+}
+
+// Split-K form of ll_gemm_bf16 (gemm_kernel_v4sk): same arguments plus a workspace.  Taken when N is a multiple of 256, K a
+// multiple of 128 and the 2 x (M / 256) x (N / 256) workgroups fit the device in one round; every other shape runs ll_gemm_bf16's
+// kernels (the workspace is then unused).  workspace: >= ll_gemm_splitk_workspace_bytes(M, N) bytes, 16-byte aligned, ZEROED
+// once by the caller before its first use and afterwards owned by the launches of ONE stream (the kernel leaves its flags zero).
+static int splitk_tiles(int M, int N) { return ((M + 255) / 256) * (N / 256); }
+static int device_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+static bool splitk_eligible(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || N % 256 != 0 || K % 128 != 0 || K < 1024) return false;
+  const int tiles = splitk_tiles(M, N);
+  const int grid = 16 * ((tiles + 7) / 8);
+  return tiles * 2 <= 1024 && grid <= device_cus();            // every workgroup resident at once: partners wait for each other
+}
+extern "C" long long ll_gemm_splitk_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0 || N % 256 != 0) return 0;
+  return (long long)V4SK_FLAG_BYTES + (long long)splitk_tiles(M, N) * 2 * V4SK_PART_FLOATS * 4;
+}
+extern "C" int ll_gemm_splitk_plan(int M, int N, int K) { return splitk_eligible(M, N, K) ? 1 : 0; }
+
+extern "C" int ll_gemm_bf16_splitk(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K,
+                                   int ldx, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,
+                                   int nmod, int gate_idx, int rows_per_batch, int frame_len, void* workspace,
+                                   long long workspace_bytes, ll_stream stream) {
+  LL_REQUIRE(K > 0 && K % 64 == 0, "ll_gemm_bf16_splitk: K=%d must be a positive multiple of 64", K);
+  LL_REQUIRE(ldx >= K && ldx % 8 == 0, "ll_gemm_bf16_splitk: ldx=%d must be >= K and a multiple of 8", ldx);
+  int rc = check_epilogue("ll_gemm_bf16_splitk", M, N, ldo, epilogue, bias, res, e, mod, nmod, gate_idx, rows_per_batch, frame_len);
+  if (rc) return rc;
+  if (M == 0) return LL_OK;
+  EpiArgs ea{(const bf16*)bias, (const bf16*)res, (const bf16*)e, (const bf16*)mod, nullptr, nullptr, nmod, gate_idx,
+             rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (!splitk_eligible(M, N, K) || workspace == nullptr) {
+    launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, s);
+    return ll_check_launch("ll_gemm_bf16_splitk(unsplit)");
+  }
+  LL_REQUIRE(workspace_bytes >= ll_gemm_splitk_workspace_bytes(M, N) && ((size_t)workspace & 15) == 0,
+             "ll_gemm_bf16_splitk: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes,
+             ll_gemm_splitk_workspace_bytes(M, N));
+  const int tiles = splitk_tiles(M, N), ntn = N / 256, nkh = K / 128;
+  dim3 grid(16 * ((tiles + 7) / 8)), block(512);
+  unsigned* flags = (unsigned*)workspace;
+  float* part = (float*)((char*)workspace + V4SK_FLAG_BYTES);
+  const size_t lds = 2 * V3_STAGE;
+#define SK_LAUNCH(E)                                                                                                   \
+  do {                                                                                                                 \
+    static bool ask = false;                                                                                           \
+    if (!ask) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      ask = true;                                                                                                      \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gemm_kernel_v4sk<E>), grid, block, lds, s, (const char*)x, (const char*)w, (bf16*)out, M, N, nkh, \
+                       (size_t)ldx * 2, (size_t)K * 2, ldo, tiles, ntn, part, flags, ea);                               \
+  } while (0)
+  switch (epilogue) {
+    case LL_EPI_BIAS: SK_LAUNCH(LL_EPI_BIAS); break;
+    case LL_EPI_BIAS_GELU: SK_LAUNCH(LL_EPI_BIAS_GELU); break;
+    case LL_EPI_BIAS_GATE_RES: SK_LAUNCH(LL_EPI_BIAS_GATE_RES); break;
+    default: SK_LAUNCH(LL_EPI_BIAS_RES); break;
+  }
+#undef SK_LAUNCH
+  return ll_check_launch("ll_gemm_bf16_splitk");
 }
 
 extern "C" int ll_gemm_w8a8(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias,

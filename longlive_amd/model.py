@@ -22,6 +22,7 @@ from .synth import WanConfig
 bf16 = torch.bfloat16
 
 
+
 class _Lin(nn.Module):
     def __init__(self, out_f: int, in_f: int, device, dtype):
         super().__init__()
@@ -136,6 +137,7 @@ class CausalWanModelHIP(nn.Module):
         self.quant: Optional[str] = None
         self.use_modulation_table = True      # modulation + e0 once per (layer, frame) instead of once per token row (A/B switch)
         self.fuse_v_insert = True             # the QKV projection's epilogue writes V into the KV cache (A/B switch)
+        self.ffn2_splitk = True               # FFN2 as 256x256 tiles x split-K 2 (ll_gemm_bf16_splitk; A/B switch, bf16 path only)
         self._packed = None
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -221,6 +223,7 @@ class CausalWanModelHIP(nn.Module):
         """One block linear: bf16 MFMA GEMM, or W8A8 GEMM in int8 mode (same fused epilogues).  In int8 mode `x` is either
         a bf16 tensor (quantised here, per token) or an already quantised (int8, scale) pair from a fused producer."""
         if self.quant == "int8":
+            kw.pop("splitk", None)
             xq, sx = x if isinstance(x, tuple) else ops.quantize_rows(x)
             return ops.gemm_w8a8(xq, sx, pk["q_" + key], pk["s_" + key], b, epilogue, tag="gemm_" + key, **kw)
         return ops.gemm(x, w, b, epilogue, tag="gemm_" + key, **kw)
@@ -357,7 +360,7 @@ class CausalWanModelHIP(nn.Module):
         h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 3, 4, F, c.eps)
         ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
         self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs)
+                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs, splitk=self.ffn2_splitk)
         return plan
 
     # ---- forward -----------------------------------------------------------------------------------------------

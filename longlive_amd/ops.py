@@ -224,8 +224,9 @@ def kv_roll(cache_k, cache_v, dst: int, src: int, n: int):
 
 
 def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
-         rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm"):
-    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias).  x may be any [..., K] contiguous tensor."""
+         rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm", splitk: bool = False):
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias).  x may be any [..., K] contiguous tensor.  splitk: the split-K kernel for
+    long-K / narrow-N shapes (ll_gemm_bf16_splitk; shapes it does not cover run the ordinary kernels)."""
     _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias")
     K = x.shape[-1]
     M = x.numel() // K
@@ -248,11 +249,33 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
             assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
-    _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
-                                _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
-               "ll_gemm_bf16")
+    if splitk:
+        ws = splitk_workspace(x.device, M, N)
+        _lib.check(lib.ll_gemm_bf16_splitk(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
+                                           _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len,
+                                           ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_bf16_splitk")
+    else:
+        _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
+                                    _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
+                   "ll_gemm_bf16")
     _t1(tag, t0, 2.0 * M * N * K)
     return out
+
+
+_splitk_ws = {}
+
+
+def splitk_workspace(device, M: int, N: int) -> torch.Tensor:
+    """Zeroed scratch for ll_gemm_bf16_splitk, one buffer per (device, STREAM): the kernel's hand-off flags and partial tiles belong
+    to the launches of one stream at a time (two streams may run the same projection concurrently: overlap_context)."""
+    lib = _lib.load()
+    need = int(lib.ll_gemm_splitk_workspace_bytes(M, N))
+    key = (device.type, device.index, int(_stream() or 0))
+    buf = _splitk_ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(max(need, 16), dtype=torch.uint8, device=device)
+        _splitk_ws[key] = buf
+    return buf
 
 
 def gemm_qkv_v_insert(x, w, bias, cache_v, write_start: int, roped_offset: int, write_len: int, xq=None, tag: str = "gemm_qkv"):

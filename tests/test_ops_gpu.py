@@ -397,3 +397,65 @@ def test_qkv_projection_with_v_insert_is_bit_identical(ops, B, F, hp, wp, H, K, 
             assert torch.equal(u, v_), f"{nm} differs (int8={int8})"
         mask = torch.ones(S, dtype=torch.bool); mask[ws:ws + wl] = False
         assert torch.equal(bq[2][:, mask], cv0[:, mask])
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4680, 1536, 8960, "gate"), (4680, 1536, 8960, "bias"), (1560, 1536, 8960, "res"),
+                                       (300, 512, 1024, "gelu"), (4680, 1536, 1536, "bias"), (300, 136, 1024, "bias")])
+def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
+    """ll_gemm_bf16_splitk (256 x 256 tiles, K cut in two, halves exchanged through the workspace inside the kernel) against
+    ll_gemm_bf16: same products, the fp32 sum split once more -> <= 1 bf16 ulp apart; 30 repeated launches are bit-identical
+    (a stale or torn hand-off would show up as a run-to-run difference) and leave the workspace flags at zero."""
+    from longlive_amd import _lib
+    x = hn("skx", (M, K)).to(DEV)
+    w = (hn("skw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("skb", (N,), 0.1).to(DEV)
+    kw = {}
+    code = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "gate": ops.EPI_BIAS_GATE_RES, "res": ops.EPI_BIAS_RES}[epi]
+    if epi in ("gate", "res"):
+        kw["res"] = hn("skr", (M, N)).to(DEV)
+    if epi == "gate":
+        F_ = 3
+        kw.update(e=hn("ske", (1, F_, 6, N), 0.5).to(DEV), mod=hn("skm", (6, N), 0.1).to(DEV), gate_idx=5, rows_per_batch=M,
+                  frame_len=M // F_)
+    want = ops.gemm(x, w, b, code, **kw)
+    eligible = _lib.load().ll_gemm_splitk_plan(M, N, K) == 1
+    assert eligible == (N % 256 == 0)
+    first = ops.gemm(x, w, b, code, splitk=True, **kw)
+    for _ in range(30):
+        again = ops.gemm(x, w, b, code, splitk=True, **kw)
+        assert torch.equal(again, first)
+    torch.cuda.synchronize()
+    if eligible:
+        ws = ops.splitk_workspace(x.device, M, N)
+        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+        # a 1-ulp flip of bf16(acc + bias) (values up to ~4: ulp 2^-6) survives the gate / residual as an ABSOLUTE difference
+        # while the sum itself may be small: absolute bound there, ulp bound for the plain epilogues
+        fused = epi in ("gate", "res")
+        assert_bf16_close(first, want, 2 if fused else 1, 0.99, f"splitk {M}x{N}x{K} {epi}", atol=4e-2 if fused else None)
+    else:
+        assert torch.equal(first, want)
+
+
+def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
+    """The partial tiles live at fixed workspace addresses: alternate two different activations so that a partner reading the
+    PREVIOUS launch's bytes (a stale line somewhere between the two workgroups) cannot reproduce the right answer."""
+    M, N, K = 4680, 1536, 8960
+    w = (hn("fw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("fb", (N,), 0.1).to(DEV)
+    xs = [hn(f"fx{i}", (M, K)).to(DEV) for i in range(2)]
+    want = [ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True) for x in xs]
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[1])
+    for it in range(40):
+        got = ops.gemm(xs[it & 1], w, b, ops.EPI_BIAS, splitk=True)
+        assert torch.equal(got, want[it & 1]), f"launch {it}"
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                      # a second stream gets its own workspace; both run at once
+        side.wait_stream(torch.cuda.current_stream())
+        for it in range(10):
+            got2 = ops.gemm(xs[1 - (it & 1)], w, b, ops.EPI_BIAS, splitk=True)
+            assert torch.equal(got2, want[1 - (it & 1)])
+    for it in range(10):
+        got = ops.gemm(xs[it & 1], w, b, ops.EPI_BIAS, splitk=True)
+        assert torch.equal(got, want[it & 1])
+    torch.cuda.synchronize()

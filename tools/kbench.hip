@@ -289,6 +289,12 @@ int main(int argc, char** argv) {
     bench_shipped(iters);
     return 0;
   }
+  if (!strcmp(what, "gemmx")) {      // kbench gemmx <iters> M N K epi [gemm_variant]: one custom shape
+    if (argc < 7) { printf("usage: kbench gemmx iters M N K epi [variant]\n"); return 1; }
+    if (argc > 7) LL(ll_set_tuning("gemm_variant", atoi(argv[7])));
+    bench_gemm("custom", atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), iters);
+    return 0;
+  }
   if (all || !strcmp(what, "gemm")) {
    for (int variant = 2; variant <= 6; ++variant) {
     LL(ll_set_tuning("gemm_variant", variant));
