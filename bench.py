@@ -230,7 +230,7 @@ def _plan_text(fn, *a):
     return buf.value.decode()
 
 
-def kernel_table(summary, quant):
+def kernel_table(summary, quant, splitk=False):
     """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac)."""
     from longlive_amd import _lib
     lib = _lib.load()
@@ -249,6 +249,10 @@ def kernel_table(summary, quant):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
             name = _plan_text(lib.ll_gemm_plan, *gemm_shapes[tag], i8)
+            if tag == "gemm_f2" and splitk and not i8 and lib.ll_gemm_splitk_plan(*gemm_shapes[tag]) == 1:
+                M_, N_, _ = gemm_shapes[tag]
+                name = (f"gemm_kernel_v4sk<bf16> tile 256x256 x split-K 2, {2 * ((M_ + 255) // 256) * (N_ // 256)} workgroups, "
+                        "halves reduced in the epilogue")
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)
         elif tag == "flash_attn_cross":
@@ -456,7 +460,7 @@ def run_replica(args, rank, world, local_rank, sync):
             blk_ms = 1e3 * (time.perf_counter() - t0)
             summ = ops.timer.summary()
             ops.timer = None
-            rows = kernel_table(summ, quant)
+            rows = kernel_table(summ, quant, splitk=bool(getattr(gen.model, "ffn2_splitk", False)))
             res["kernels"] = {"note": "one untimed steady-state block, HIP events around every launch (adds ~2 us of gap per launch: "
                                       f"this block took {blk_ms:.1f} ms); shares are of the sum of kernel time",
                               "sum_kernel_ms": sum(r["total_ms"] for r in rows), "rows": rows}
