@@ -249,9 +249,9 @@ def kernel_table(summary, quant, splitk=False):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
             name = _plan_text(lib.ll_gemm_plan, *gemm_shapes[tag], i8)
-            if tag == "gemm_f2" and splitk and not i8 and lib.ll_gemm_splitk_plan(*gemm_shapes[tag]) == 1:
+            if tag == "gemm_f2" and splitk and lib.ll_gemm_splitk_plan(*gemm_shapes[tag], i8) == 1:
                 M_, N_, _ = gemm_shapes[tag]
-                name = (f"gemm_kernel_v4sk<bf16> tile 256x256 x split-K 2, {2 * ((M_ + 255) // 256) * (N_ // 256)} workgroups, "
+                name = (f"gemm_kernel_v4sk<{'i8' if i8 else 'bf16'}> tile 256x256 x split-K 2, {2 * ((M_ + 255) // 256) * (N_ // 256)} workgroups, "
                         "halves reduced in the epilogue")
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)

@@ -118,7 +118,7 @@ int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf1
 
 /* Split-K form of ll_gemm_bf16 for long-K, 1536-wide projections (ffn.2, wan/modules/causal_model.py:406-408,462-468): 256 x 256
  * tiles with K cut in two, the halves exchanged through `workspace` and reduced inside the kernel (gemm_kernel_v4sk), same fused
- * epilogues, same arguments.  Taken when ll_gemm_splitk_plan(M, N, K) == 1 (N % 256 == 0, K % 128 == 0, K >= 1024 and the
+ * epilogues, same arguments.  Taken when ll_gemm_splitk_plan(M, N, K, 0) == 1 (N % 256 == 0, K % 128 == 0, K >= 1024 and the
  * 2 x ceil(M / 256) x (N / 256) workgroups fit the device in one round) and workspace != NULL; otherwise it IS ll_gemm_bf16.
  * workspace: >= ll_gemm_splitk_workspace_bytes(M, N) bytes of 16-byte-aligned device memory, zeroed ONCE by the caller before its
  * first use (the kernel leaves its flags zero) and used by the launches of one stream at a time.  Results equal ll_gemm_bf16's up
@@ -128,7 +128,12 @@ int ll_gemm_bf16_splitk(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias,
                         int gate_idx, int rows_per_batch, int frame_len, void* workspace, long long workspace_bytes,
                         ll_stream stream);
 long long ll_gemm_splitk_workspace_bytes(int M, int N);
-int ll_gemm_splitk_plan(int M, int N, int K);
+int ll_gemm_splitk_plan(int M, int N, int K, int int8);
+/* ... and of ll_gemm_w8a8 (int32 partial sums: the exchange is exact, the result equals ll_gemm_w8a8's bit for bit). */
+int ll_gemm_w8a8_splitk(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias, ll_bf16* out,
+                        int M, int N, int K, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,
+                        int nmod, int gate_idx, int rows_per_batch, int frame_len, void* workspace, long long workspace_bytes,
+                        ll_stream stream);
 
 /* W8A8 variant of ll_gemm_bf16 for BASELINE config 5 ("INT8-quantized linear layers"; the reference ships no INT8 code,
  * reports.md:24,39): out = epilogue(sx[m] * sw[n] * (xq[M,K] . wq[N,K]^T) + bias) with int8 operands, exact int32

@@ -499,12 +499,13 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict_
 #define V4SK_PART_FLOATS (8 * 16 * 64 * 4)      // per (tile, split): [wave][a][b'][lane][4]
 #define V4SK_FLAG_BYTES 4096
 
-__device__ __forceinline__ void sk_store_sc1(float* p, f32x4 v) {
+template <typename V>
+__device__ __forceinline__ void sk_store_sc1(float* p, V v) {      // f32x4 partial sums, or i32x4 (W8A8: exact integers)
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int EPI, int SPLIT>
-__device__ __forceinline__ void v4sk_finish(f32x4 (&acc)[4][8], float* __restrict__ part, unsigned* __restrict__ flags, int tile,
+template <int EPI, bool I8, int SPLIT>
+__device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], float* __restrict__ part, unsigned* __restrict__ flags, int tile,
                                             bf16* __restrict__ Y, int M, int N, int ldo, int mw, int nw, int wave, int lane,
                                             const EpiArgs& ea) {
   constexpr int GIVE = SPLIT ^ 1;
@@ -527,11 +528,12 @@ __device__ __forceinline__ void v4sk_finish(f32x4 (&acc)[4][8], float* __restric
     __hip_atomic_store(pf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this workspace
   }
   __syncthreads();
-  f32x4 hlo[4][2], hhi[4][2];     // two 32-row halves: the gate-residual epilogue of a 64-row batch does not fit the register file
+  typedef typename Ty<I8>::acc acc_t;
+  acc_t hlo[4][2], hhi[4][2];     // two 32-row halves: the gate-residual epilogue of a 64-row batch does not fit the register file
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const float* q = theirs + a * 4 * 256;
-    f32x4 r0, r1, r2, r3;
+    acc_t r0, r1, r2, r3;
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc1\n\t"
         "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
@@ -546,17 +548,16 @@ __device__ __forceinline__ void v4sk_finish(f32x4 (&acc)[4][8], float* __restric
     hhi[a][0] = acc[a][SPLIT * 4 + 2] + r2;
     hhi[a][1] = acc[a][SPLIT * 4 + 3] + r3;
   }
-  gemm_epilogue<EPI, false, 4, 2>(hlo, Y, M, N, ldo, mw + SPLIT * 64, nw, lane & 15, lane >> 4, ea);
-  gemm_epilogue<EPI, false, 4, 2>(hhi, Y, M, N, ldo, mw + SPLIT * 64 + 32, nw, lane & 15, lane >> 4, ea);
+  gemm_epilogue<EPI, I8, 4, 2>(hlo, Y, M, N, ldo, mw + SPLIT * 64, nw, lane & 15, lane >> 4, ea);
+  gemm_epilogue<EPI, I8, 4, 2>(hhi, Y, M, N, ldo, mw + SPLIT * 64 + 32, nw, lane & 15, lane >> 4, ea);
 }
 
-template <int EPI>
+template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restrict__ X, const char* __restrict__ Wt,
                                                            bf16* __restrict__ Y, int M, int N, int nkh, size_t xrow_bytes,
                                                            size_t wrow_bytes, int ldo, int ntiles, int ntn,
                                                            float* __restrict__ part, unsigned* __restrict__ flags, EpiArgs ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool I8 = false;
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restric
   const int m0 = mt_ * V3_BM, n0 = nt_ * V3_BN;
   const int k0 = split * nkh;
 
-  f32x4 acc[4][8];
+  typename Ty<I8>::acc acc[4][8];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -616,8 +617,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restric
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (split == 0) v4sk_finish<EPI, 0>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
-  else v4sk_finish<EPI, 1>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+  if (split == 0) v4sk_finish<EPI, I8, 0>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+  else v4sk_finish<EPI, I8, 1>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
 }
 #undef V4_LOAD_A
 #undef V4_LOAD_B
@@ -910,8 +911,8 @@ static int device_cus() {
   }
   return cus[dev] > 0 ? cus[dev] : 0;
 }
-static bool splitk_eligible(int M, int N, int K) {
-  if (M <= 0 || N <= 0 || N % 256 != 0 || K % 128 != 0 || K < 1024) return false;
+static bool splitk_eligible(int M, int N, int kbytes) {      // kbytes = bytes of K per operand row (bf16: 2 K, int8: K)
+  if (M <= 0 || N <= 0 || N % 256 != 0 || kbytes % 256 != 0 || kbytes < 2048) return false;
   const int tiles = splitk_tiles(M, N);
   const int grid = 16 * ((tiles + 7) / 8);
   return tiles * 2 <= 1024 && grid <= device_cus();            // every workgroup resident at once: partners wait for each other
@@ -920,7 +921,43 @@ extern "C" long long ll_gemm_splitk_workspace_bytes(int M, int N) {
   if (M <= 0 || N <= 0 || N % 256 != 0) return 0;
   return (long long)V4SK_FLAG_BYTES + (long long)splitk_tiles(M, N) * 2 * V4SK_PART_FLOATS * 4;
 }
-extern "C" int ll_gemm_splitk_plan(int M, int N, int K) { return splitk_eligible(M, N, K) ? 1 : 0; }
+extern "C" int ll_gemm_splitk_plan(int M, int N, int K, int int8) { return splitk_eligible(M, N, int8 ? K : 2 * K) ? 1 : 0; }
+
+template <bool I8>
+static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out, int M, int N, int K, size_t xrow_bytes,
+                         size_t wrow_bytes, int ldo, int epilogue, const EpiArgs& ea, void* workspace, long long workspace_bytes,
+                         hipStream_t s) {
+  const int kbytes = I8 ? K : 2 * K;
+  if (!splitk_eligible(M, N, kbytes) || workspace == nullptr) {
+    launch_gemm<I8>(x, w, out, M, N, K, xrow_bytes, wrow_bytes, ldo, epilogue, ea, s);
+    return ll_check_launch(fn);
+  }
+  LL_REQUIRE(workspace_bytes >= ll_gemm_splitk_workspace_bytes(M, N) && ((size_t)workspace & 15) == 0,
+             "%s: workspace of %lld bytes, need %lld (16-byte aligned)", fn, workspace_bytes, ll_gemm_splitk_workspace_bytes(M, N));
+  const int tiles = splitk_tiles(M, N), ntn = N / 256, nkh = kbytes / (2 * ROWB);
+  dim3 grid(16 * ((tiles + 7) / 8)), block(512);
+  unsigned* flags = (unsigned*)workspace;
+  float* part = (float*)((char*)workspace + V4SK_FLAG_BYTES);
+  const size_t lds = 2 * V3_STAGE;
+#define SK_LAUNCH(E)                                                                                                   \
+  do {                                                                                                                 \
+    static bool ask = false;                                                                                           \
+    if (!ask) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      ask = true;                                                                                                      \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh,  \
+                       xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea);                                      \
+  } while (0)
+  switch (epilogue) {
+    case LL_EPI_BIAS: SK_LAUNCH(LL_EPI_BIAS); break;
+    case LL_EPI_BIAS_GELU: SK_LAUNCH(LL_EPI_BIAS_GELU); break;
+    case LL_EPI_BIAS_GATE_RES: SK_LAUNCH(LL_EPI_BIAS_GATE_RES); break;
+    default: SK_LAUNCH(LL_EPI_BIAS_RES); break;
+  }
+#undef SK_LAUNCH
+  return ll_check_launch(fn);
+}
 
 extern "C" int ll_gemm_bf16_splitk(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K,
                                    int ldx, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,
@@ -933,37 +970,23 @@ extern "C" int ll_gemm_bf16_splitk(const ll_bf16* x, const ll_bf16* w, const ll_
   if (M == 0) return LL_OK;
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, (const bf16*)e, (const bf16*)mod, nullptr, nullptr, nmod, gate_idx,
              rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
-  hipStream_t s = (hipStream_t)stream;
-  if (!splitk_eligible(M, N, K) || workspace == nullptr) {
-    launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, s);
-    return ll_check_launch("ll_gemm_bf16_splitk(unsplit)");
-  }
-  LL_REQUIRE(workspace_bytes >= ll_gemm_splitk_workspace_bytes(M, N) && ((size_t)workspace & 15) == 0,
-             "ll_gemm_bf16_splitk: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes,
-             ll_gemm_splitk_workspace_bytes(M, N));
-  const int tiles = splitk_tiles(M, N), ntn = N / 256, nkh = K / 128;
-  dim3 grid(16 * ((tiles + 7) / 8)), block(512);
-  unsigned* flags = (unsigned*)workspace;
-  float* part = (float*)((char*)workspace + V4SK_FLAG_BYTES);
-  const size_t lds = 2 * V3_STAGE;
-#define SK_LAUNCH(E)                                                                                                   \
-  do {                                                                                                                 \
-    static bool ask = false;                                                                                           \
-    if (!ask) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      ask = true;                                                                                                      \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((gemm_kernel_v4sk<E>), grid, block, lds, s, (const char*)x, (const char*)w, (bf16*)out, M, N, nkh, \
-                       (size_t)ldx * 2, (size_t)K * 2, ldo, tiles, ntn, part, flags, ea);                               \
-  } while (0)
-  switch (epilogue) {
-    case LL_EPI_BIAS: SK_LAUNCH(LL_EPI_BIAS); break;
-    case LL_EPI_BIAS_GELU: SK_LAUNCH(LL_EPI_BIAS_GELU); break;
-    case LL_EPI_BIAS_GATE_RES: SK_LAUNCH(LL_EPI_BIAS_GATE_RES); break;
-    default: SK_LAUNCH(LL_EPI_BIAS_RES); break;
-  }
-#undef SK_LAUNCH
-  return ll_check_launch("ll_gemm_bf16_splitk");
+  return launch_splitk<false>("ll_gemm_bf16_splitk", x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea,
+                              workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ll_gemm_w8a8_splitk(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias,
+                                   ll_bf16* out, int M, int N, int K, int ldo, int epilogue, const ll_bf16* res,
+                                   const ll_bf16* e, const ll_bf16* mod, int nmod, int gate_idx, int rows_per_batch,
+                                   int frame_len, void* workspace, long long workspace_bytes, ll_stream stream) {
+  LL_REQUIRE(K > 0 && K % 128 == 0, "ll_gemm_w8a8_splitk: K=%d must be a positive multiple of 128", K);
+  LL_REQUIRE(sx && sw, "ll_gemm_w8a8_splitk: activation and weight scales are required");
+  int rc = check_epilogue("ll_gemm_w8a8_splitk", M, N, ldo, epilogue, bias, res, e, mod, nmod, gate_idx, rows_per_batch, frame_len);
+  if (rc) return rc;
+  if (M == 0) return LL_OK;
+  EpiArgs ea{(const bf16*)bias, (const bf16*)res, (const bf16*)e, (const bf16*)mod, sx, sw, nmod, gate_idx,
+             rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
+  return launch_splitk<true>("ll_gemm_w8a8_splitk", xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, epilogue, ea, workspace,
+                             workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int ll_gemm_w8a8(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias,

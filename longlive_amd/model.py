@@ -137,7 +137,7 @@ class CausalWanModelHIP(nn.Module):
         self.quant: Optional[str] = None
         self.use_modulation_table = True      # modulation + e0 once per (layer, frame) instead of once per token row (A/B switch)
         self.fuse_v_insert = True             # the QKV projection's epilogue writes V into the KV cache (A/B switch)
-        self.ffn2_splitk = True               # FFN2 as 256x256 tiles x split-K 2 (ll_gemm_bf16_splitk; A/B switch, bf16 path only)
+        self.ffn2_splitk = True               # FFN2 as 256x256 tiles x split-K 2 (ll_gemm_bf16_splitk / ll_gemm_w8a8_splitk; A/B switch)
         self._packed = None
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -223,7 +223,7 @@ class CausalWanModelHIP(nn.Module):
         """One block linear: bf16 MFMA GEMM, or W8A8 GEMM in int8 mode (same fused epilogues).  In int8 mode `x` is either
         a bf16 tensor (quantised here, per token) or an already quantised (int8, scale) pair from a fused producer."""
         if self.quant == "int8":
-            kw.pop("splitk", None)
+            kw.pop("splitk", None)      # W8A8 FFN2: the split-K form measured 76.6 -> 88 us (half the K-steps, same exchange): not used
             xq, sx = x if isinstance(x, tuple) else ops.quantize_rows(x)
             return ops.gemm_w8a8(xq, sx, pk["q_" + key], pk["s_" + key], b, epilogue, tag="gemm_" + key, **kw)
         return ops.gemm(x, w, b, epilogue, tag="gemm_" + key, **kw)

@@ -336,7 +336,7 @@ def quantize_rows(x, q=None, scale=None):
 
 
 def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
-              rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm"):
+              rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm", splitk: bool = False):
     """out[M,N] = epilogue(sx[m] sw[n] (xq[M,K] @ wq[N,K]^T) + bias): int8 operands, int32 accumulation, bf16 out."""
     _chk(xq, "xq", torch.int8); _chk(wq, "wq", torch.int8); _chk(sx, "sx", torch.float32); _chk(sw, "sw", torch.float32)
     _chk(bias, "bias")
@@ -361,9 +361,15 @@ def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None
             assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
-    _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
-                                out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
-                                rows_per_batch, frame_len, _stream()), "ll_gemm_w8a8")
+    if splitk:
+        ws = splitk_workspace(xq.device, M, N)
+        _lib.check(lib.ll_gemm_w8a8_splitk(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+                                           out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
+                                           rows_per_batch, frame_len, ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_w8a8_splitk")
+    else:
+        _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+                                    out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
+                                    rows_per_batch, frame_len, _stream()), "ll_gemm_w8a8")
     _t1(tag, t0, 2.0 * M * N * K)
     return out
 

@@ -418,7 +418,7 @@ def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
         kw.update(e=hn("ske", (1, F_, 6, N), 0.5).to(DEV), mod=hn("skm", (6, N), 0.1).to(DEV), gate_idx=5, rows_per_batch=M,
                   frame_len=M // F_)
     want = ops.gemm(x, w, b, code, **kw)
-    eligible = _lib.load().ll_gemm_splitk_plan(M, N, K) == 1
+    eligible = _lib.load().ll_gemm_splitk_plan(M, N, K, 0) == 1
     assert eligible == (N % 256 == 0)
     first = ops.gemm(x, w, b, code, splitk=True, **kw)
     for _ in range(30):
@@ -458,4 +458,22 @@ def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
     for it in range(10):
         got = ops.gemm(xs[it & 1], w, b, ops.EPI_BIAS, splitk=True)
         assert torch.equal(got, want[it & 1])
+    torch.cuda.synchronize()
+
+
+def test_gemm_w8a8_splitk_is_exact(ops):
+    """W8A8 split-K: the halves exchange int32 sums, so the result equals the unsplit kernel's bit for bit."""
+    M, N, K = 4680, 1536, 8960
+    x = hn("qx", (M, K)).to(DEV)
+    w = (hn("qw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("qb", (N,), 0.1).to(DEV)
+    xq, sx = ops.quantize_rows(x)
+    wq, sw = ops.quantize_rows(w)
+    res = hn("qr", (M, N)).to(DEV)
+    kw = dict(res=res, e=hn("qe", (1, 3, 6, N), 0.5).to(DEV), mod=hn("qm", (6, N), 0.1).to(DEV), gate_idx=5, rows_per_batch=M,
+              frame_len=M // 3)
+    want = ops.gemm_w8a8(xq, sx, wq, sw, b, ops.EPI_BIAS_GATE_RES, **kw)
+    for _ in range(10):
+        got = ops.gemm_w8a8(xq, sx, wq, sw, b, ops.EPI_BIAS_GATE_RES, splitk=True, **kw)
+        assert torch.equal(got, want)
     torch.cuda.synchronize()
