@@ -219,17 +219,25 @@ static void bench_shipped(int iters) {
     Buf x((size_t)L * g.K, 1.0f), w((size_t)g.N * g.K, 1.0f / sqrtf((float)g.K)), bias(g.N, 0.1f), out((size_t)L * g.N, 0.f);
     Buf res((size_t)L * g.N, 1.0f), e((size_t)3 * 6 * g.N, 0.5f);
     const bool qkv = !strcmp(g.tag, "gemm_qkv");
+    const bool sk = !strcmp(g.tag, "gemm_f2") && !getenv("KBENCH_NO_SPLITK") && ll_gemm_splitk_plan(L, g.N, g.K, 0) == 1;
+    void* skws = nullptr;
+    long long skb = sk ? ll_gemm_splitk_workspace_bytes(L, g.N) : 0;
+    if (sk) { CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb)); }
     double ms = time_ms(s, iters, [&]() {
       if (qkv)      // as shipped: the V third goes straight into the KV cache
         LL(ll_gemm_bf16_qkv(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, vcache.d, 1, L, S, S - L, 0, L, s));
+      else if (sk)  // as shipped: FFN2 = 256x256 tiles x split-K 2
+        LL(ll_gemm_bf16_splitk(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, nullptr, 6, 2, L, FS, skws, skb, s));
       else          // as shipped: `e` is a layer's slice of ll_modulation_table (mod = NULL)
         LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, nullptr, 6, 2, L, FS, s));
     });
+    if (skws) CK(hipFree(skws));
     LL(ll_gemm_plan(L, g.N, g.K, 0, plan, sizeof plan));
+    if (sk) snprintf(plan, sizeof plan, "gemm_kernel_v4sk<bf16> tile 256x256 x split-K 2, 228 workgroups");
     double fl = 2.0 * L * g.N * g.K, by = 2.0 * ((double)L * g.K + (double)g.N * g.K + (double)L * g.N * (g.epi >= 2 ? 2 : 1));
     printf("%-10s %-60s %8.1f us %7.1f TFLOP/s\n", g.tag, plan, ms * 1e3, fl / (ms * 1e-3) / 1e12);
     char match[64];
-    snprintf(match, sizeof match, "%.14s<%d", plan, g.epi);      // gemm_kernel_vN<EPI
+    snprintf(match, sizeof match, sk ? "%.16s<%d" : "%.14s<%d", plan, g.epi);      // gemm_kernel_vN<EPI / gemm_kernel_v4sk<EPI
     work_line(g.tag, match, fl, by, ms * 1e3, "mfma");
   }
   {
