@@ -529,24 +529,42 @@ __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], f
   }
   __syncthreads();
   typedef typename Ty<I8>::acc acc_t;
+  // all 16 loads of the partner's half in flight, ONE wait (four dependent round trips cost ~4 us of every launch)
+  acc_t r[4][4];
+  const float* q0 = theirs;
+  const float* q1 = theirs + 4 * 256;
+  const float* q2 = theirs + 8 * 256;
+  const float* q3 = theirs + 12 * 256;
+  asm volatile(
+      "global_load_dwordx4 %0, %16, off sc1\n\t"
+      "global_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %4, %17, off sc1\n\t"
+      "global_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %8, %18, off sc1\n\t"
+      "global_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %12, %19, off sc1\n\t"
+      "global_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]),
+        "=&v"(r[1][3]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3]), "=&v"(r[3][0]), "=&v"(r[3][1]),
+        "=&v"(r[3][2]), "=&v"(r[3][3])
+      : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+      : "memory");
   acc_t hlo[4][2], hhi[4][2];     // two 32-row halves: the gate-residual epilogue of a 64-row batch does not fit the register file
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const float* q = theirs + a * 4 * 256;
-    acc_t r0, r1, r2, r3;
-    asm volatile(
-        "global_load_dwordx4 %0, %4, off sc1\n\t"
-        "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
-        "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
-        "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-        : "v"(q)
-        : "memory");
-    hlo[a][0] = acc[a][SPLIT * 4 + 0] + r0;
-    hlo[a][1] = acc[a][SPLIT * 4 + 1] + r1;
-    hhi[a][0] = acc[a][SPLIT * 4 + 2] + r2;
-    hhi[a][1] = acc[a][SPLIT * 4 + 3] + r3;
+    hlo[a][0] = acc[a][SPLIT * 4 + 0] + r[a][0];
+    hlo[a][1] = acc[a][SPLIT * 4 + 1] + r[a][1];
+    hhi[a][0] = acc[a][SPLIT * 4 + 2] + r[a][2];
+    hhi[a][1] = acc[a][SPLIT * 4 + 3] + r[a][3];
   }
   gemm_epilogue<EPI, I8, 4, 2>(hlo, Y, M, N, ldo, mw + SPLIT * 64, nw, lane & 15, lane >> 4, ea);
   gemm_epilogue<EPI, I8, 4, 2>(hhi, Y, M, N, ldo, mw + SPLIT * 64 + 32, nw, lane & 15, lane >> 4, ea);
