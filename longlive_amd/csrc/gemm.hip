@@ -494,17 +494,22 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict_
 //   the launcher only takes this path when the whole grid fits the device in one round (one workgroup per CU: 128 KiB LDS).
 //   Pairs are placed on ONE XCD (block b -> XCD b % 8: pair = (b / 8) / 2), so the hand-off stays in that XCD's L2 / its memory
 //   channel neighbourhood; correctness does not depend on that placement.
+//   L2 = true (taken only when a probe launch has shown that block b's XCC_ID is a function of b % 8 on this device, i.e. that
+//   partners DO share an XCD): the partial tiles use plain stores and loads -- the lines stay in the pair's L2 instead of making
+//   a round trip through memory (29 MB written and read back at the very end of the launch cost ~15 us); the flag protocol is
+//   unchanged.  The reader has never touched those addresses in this launch, so its L1 cannot hold them.
 // fp32 addition commutes: the result does not depend on which half arrives first (deterministic), but it differs in the last
 // bits from the unsplit kernels' single accumulation chain.
 #define V4SK_PART_FLOATS (8 * 16 * 64 * 4)      // per (tile, split): [wave][a][b'][lane][4]
 #define V4SK_FLAG_BYTES 4096
 
-template <typename V>
-__device__ __forceinline__ void sk_store_sc1(float* p, V v) {      // f32x4 partial sums, or i32x4 (W8A8: exact integers)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+template <bool L2, typename V>
+__device__ __forceinline__ void sk_store(float* p, V v) {      // f32x4 partial sums, or i32x4 (W8A8: exact integers)
+  if (L2) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int EPI, bool I8, int SPLIT>
+template <int EPI, bool I8, int SPLIT, bool L2>
 __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], float* __restrict__ part, unsigned* __restrict__ flags, int tile,
                                             bf16* __restrict__ Y, int M, int N, int ldo, int mw, int nw, int wave, int lane,
                                             const EpiArgs& ea) {
@@ -514,7 +519,7 @@ __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], f
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) sk_store_sc1(mine + (a * 4 + b) * 256, acc[a][GIVE * 4 + b]);
+    for (int b = 0; b < 4; ++b) sk_store<L2>(mine + (a * 4 + b) * 256, acc[a][GIVE * 4 + b]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -535,29 +540,55 @@ __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], f
   const float* q1 = theirs + 4 * 256;
   const float* q2 = theirs + 8 * 256;
   const float* q3 = theirs + 12 * 256;
-  asm volatile(
-      "global_load_dwordx4 %0, %16, off sc1\n\t"
-      "global_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
-      "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
-      "global_load_dwordx4 %4, %17, off sc1\n\t"
-      "global_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
-      "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
-      "global_load_dwordx4 %8, %18, off sc1\n\t"
-      "global_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
-      "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
-      "global_load_dwordx4 %12, %19, off sc1\n\t"
-      "global_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
-      "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]),
-        "=&v"(r[1][3]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3]), "=&v"(r[3][0]), "=&v"(r[3][1]),
-        "=&v"(r[3][2]), "=&v"(r[3][3])
-      : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
-      : "memory");
+  if (L2) {
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off\n\t"
+        "global_load_dwordx4 %1, %16, off offset:1024\n\t"
+        "global_load_dwordx4 %2, %16, off offset:2048\n\t"
+        "global_load_dwordx4 %3, %16, off offset:3072\n\t"
+        "global_load_dwordx4 %4, %17, off\n\t"
+        "global_load_dwordx4 %5, %17, off offset:1024\n\t"
+        "global_load_dwordx4 %6, %17, off offset:2048\n\t"
+        "global_load_dwordx4 %7, %17, off offset:3072\n\t"
+        "global_load_dwordx4 %8, %18, off\n\t"
+        "global_load_dwordx4 %9, %18, off offset:1024\n\t"
+        "global_load_dwordx4 %10, %18, off offset:2048\n\t"
+        "global_load_dwordx4 %11, %18, off offset:3072\n\t"
+        "global_load_dwordx4 %12, %19, off\n\t"
+        "global_load_dwordx4 %13, %19, off offset:1024\n\t"
+        "global_load_dwordx4 %14, %19, off offset:2048\n\t"
+        "global_load_dwordx4 %15, %19, off offset:3072\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]),
+          "=&v"(r[1][3]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3]), "=&v"(r[3][0]), "=&v"(r[3][1]),
+          "=&v"(r[3][2]), "=&v"(r[3][3])
+        : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+        : "memory");
+  } else {
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off sc1\n\t"
+        "global_load_dwordx4 %1, %16, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %2, %16, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %3, %16, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %4, %17, off sc1\n\t"
+        "global_load_dwordx4 %5, %17, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %6, %17, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %7, %17, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %8, %18, off sc1\n\t"
+        "global_load_dwordx4 %9, %18, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %10, %18, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %11, %18, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %12, %19, off sc1\n\t"
+        "global_load_dwordx4 %13, %19, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %14, %19, off offset:2048 sc1\n\t"
+        "global_load_dwordx4 %15, %19, off offset:3072 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]),
+          "=&v"(r[1][3]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3]), "=&v"(r[3][0]), "=&v"(r[3][1]),
+          "=&v"(r[3][2]), "=&v"(r[3][3])
+        : "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+        : "memory");
+  }
   acc_t hlo[4][2], hhi[4][2];     // two 32-row halves: the gate-residual epilogue of a 64-row batch does not fit the register file
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -570,7 +601,7 @@ __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], f
   gemm_epilogue<EPI, I8, 4, 2>(hhi, Y, M, N, ldo, mw + SPLIT * 64 + 32, nw, lane & 15, lane >> 4, ea);
 }
 
-template <int EPI, bool I8>
+template <int EPI, bool I8, bool L2>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restrict__ X, const char* __restrict__ Wt,
                                                            bf16* __restrict__ Y, int M, int N, int nkh, size_t xrow_bytes,
                                                            size_t wrow_bytes, int ldo, int ntiles, int ntn,
@@ -635,8 +666,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restric
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (split == 0) v4sk_finish<EPI, I8, 0>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
-  else v4sk_finish<EPI, I8, 1>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+  if (split == 0) v4sk_finish<EPI, I8, 0, L2>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+  else v4sk_finish<EPI, I8, 1, L2>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
 }
 #undef V4_LOAD_A
 #undef V4_LOAD_B
@@ -657,6 +688,7 @@ void ll_set_attn_xcd_internal(int v);
 void ll_set_attn_sk_internal(int v);
 void ll_set_attn_pp_min_internal(int v);
 void ll_set_conv_halo_internal(int v);
+void ll_set_splitk_l2_internal(int v);
 extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return LL_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return LL_OK; }
@@ -670,6 +702,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_pp_min_keys")) { ll_set_attn_pp_min_internal(value); return LL_OK; }
   if (!strcmp(key, "conv_halo")) { ll_set_conv_halo_internal(value); return LL_OK; }
+  if (!strcmp(key, "gemm_splitk_l2")) { ll_set_splitk_l2_internal(value); return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }
@@ -929,6 +962,37 @@ static int device_cus() {
   }
   return cus[dev] > 0 ? cus[dev] : 0;
 }
+__global__ void xcc_probe_kernel(unsigned* out) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = x & 15u;
+}
+static int g_gemm_splitk_l2 = 0;     // tuning key gemm_splitk_l2: 1 = exchange through the pair's L2 (plain stores / loads) when the
+                                     // placement probe allows it; measured 146.8 vs 150.9 us alone, +0.1 % in the pipeline: off
+void ll_set_splitk_l2_internal(int v) { g_gemm_splitk_l2 = v; }
+// 1 when blocks b and b + 8k of a launch run on one XCD on this device (probed once with 2048 single-wave blocks), else 0
+static int splitk_same_xcd() {
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cached[dev] == 0) {
+    cached[dev] = -1;
+    const int n = 2048;
+    unsigned* d = nullptr;
+    unsigned h[n];
+    if (hipMalloc(&d, n * sizeof(unsigned)) == hipSuccess) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(n), dim3(64), 0, 0, d);
+      if (hipMemcpy(h, d, n * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+        bool ok = true;
+        for (int i = 8; i < n && ok; ++i) ok = h[i] == h[i & 7];
+        cached[dev] = ok ? 1 : -1;
+      }
+      (void)hipFree(d);
+    }
+  }
+  return cached[dev] > 0 ? 1 : 0;
+}
+
 static bool splitk_eligible(int M, int N, int kbytes) {      // kbytes = bytes of K per operand row (bf16: 2 K, int8: K)
   if (M <= 0 || N <= 0 || N % 256 != 0 || kbytes % 256 != 0 || kbytes < 2048) return false;
   const int tiles = splitk_tiles(M, N);
@@ -957,15 +1021,21 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
   unsigned* flags = (unsigned*)workspace;
   float* part = (float*)((char*)workspace + V4SK_FLAG_BYTES);
   const size_t lds = 2 * V3_STAGE;
+  const bool l2 = g_gemm_splitk_l2 && splitk_same_xcd();
 #define SK_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
     static bool ask = false;                                                                                           \
     if (!ask) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E, I8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E, I8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       ask = true;                                                                                                      \
     }                                                                                                                  \
-    hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh,  \
-                       xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea);                                      \
+    if (l2)                                                                                                            \
+      hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8, true>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh, \
+                         xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea);                                    \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8, false>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh, \
+                         xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea);                                    \
   } while (0)
   switch (epilogue) {
     case LL_EPI_BIAS: SK_LAUNCH(LL_EPI_BIAS); break;

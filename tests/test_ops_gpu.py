@@ -461,6 +461,24 @@ def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
     torch.cuda.synchronize()
 
 
+def test_gemm_splitk_l2_exchange_matches(ops):
+    """Opt-in exchange through the pair's L2 (tuning key gemm_splitk_l2; falls back to the sc1 form when the placement probe says
+    partners do not share an XCD): same bits as the shipped exchange."""
+    from longlive_amd import _lib
+    M, N, K = 4680, 1536, 8960
+    w = (hn("lw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("lb", (N,), 0.1).to(DEV)
+    xs = [hn(f"lx{i}", (M, K)).to(DEV) for i in range(2)]
+    want = [ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True) for x in xs]
+    try:
+        assert _lib.load().ll_set_tuning(b"gemm_splitk_l2", 1) == 0
+        for it in range(20):
+            assert torch.equal(ops.gemm(xs[it & 1], w, b, ops.EPI_BIAS, splitk=True), want[it & 1]), f"launch {it}"
+    finally:
+        _lib.load().ll_set_tuning(b"gemm_splitk_l2", 0)
+    torch.cuda.synchronize()
+
+
 def test_gemm_w8a8_splitk_is_exact(ops):
     """W8A8 split-K: the halves exchange int32 sums, so the result equals the unsplit kernel's bit for bit."""
     M, N, K = 4680, 1536, 8960
