@@ -320,7 +320,10 @@ class _SideDecoder:
             v = self.vae.decode_to_pixel(latents, use_cache=True)
             self.pieces.append((v * 0.5 + 0.5).clamp(0, 1))
 
-    def finish(self) -> torch.Tensor:
+    def finish(self) -> Optional[torch.Tensor]:
+        if self.side is None:                       # no block was pushed
+            self.vae.model.clear_cache()
+            return None
         main = torch.cuda.current_stream(self.side.device)
         main.wait_stream(self.side)
         for p in self.pieces:
