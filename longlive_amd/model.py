@@ -22,8 +22,6 @@ from .synth import WanConfig
 bf16 = torch.bfloat16
 
 
-
-
 class _Lin(nn.Module):
     def __init__(self, out_f: int, in_f: int, device, dtype):
         super().__init__()
