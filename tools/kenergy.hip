@@ -102,7 +102,14 @@ int main(int argc, char** argv) {
     auto* res = (ll_bf16*)dalloc((size_t)M * N * 2, 1.0f);
     auto* e = (ll_bf16*)dalloc((size_t)3 * 6 * N * 2, 0.5f);
     auto* mod = (ll_bf16*)dalloc((size_t)6 * N * 2, 0.1f);
-    fn = [=]() { LL(ll_gemm_bf16(x, w, b, out, M, N, K, K, N, epi, res, e, mod, 6, 2, M, M / 3, s)); };
+    void* skws = nullptr;
+    long long skb = 0;
+    if (getenv("KENERGY_SPLITK")) {        // FFN2 as shipped: 256x256 tiles x split-K 2 (ll_gemm_bf16_splitk)
+      skb = ll_gemm_splitk_workspace_bytes(M, N);
+      if (skb > 0) { CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb)); }
+    }
+    if (skws) fn = [=]() { LL(ll_gemm_bf16_splitk(x, w, b, out, M, N, K, K, N, epi, res, e, mod, 6, 2, M, M / 3, skws, skb, s)); };
+    else fn = [=]() { LL(ll_gemm_bf16(x, w, b, out, M, N, K, K, N, epi, res, e, mod, 6, 2, M, M / 3, s)); };
     flops = 2.0 * M * N * K;
   }
   for (int i = 0; i < 10; ++i) fn();
