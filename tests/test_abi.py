@@ -62,6 +62,10 @@ def test_no_torch_types_in_the_abi():
     (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 1, 1, 128, 64, 60, 0, 10, None), "outside cache"),
     (lambda L: L.ll_gemm_bf16(0, 0, 1, 0, 128, 128, 128, 128, 128, 2, 0, 0, 0, 6, 2, 128, 64, None), "res and e"),
     (lambda L: L.ll_modulation_table(0, 0, 0, 30, 3, 6, 1537, None), "bad shape"),
+    (lambda L: L.ll_gemm_bf16_splitk(0, 0, 1, 0, 4680, 1536, 8960, 8000, 1536, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "ldx=8000"),
+    (lambda L: L.ll_gemm_bf16_splitk(0, 0, 1, 0, 4680, 1536, 8960, 8960, 1536, 3, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "needs res"),
+    (lambda L: L.ll_gemm_w8a8_splitk(0, 0, 0, 0, 1, 0, 4680, 1536, 8960, 1536, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "scales"),
+    (lambda L: L.ll_conv_cl(0, 1, 1, 1, 0, 1, 2, 16, 32, 96, 96, 2624, 3, 3, 0, 96, None), "null operand"),
 ])
 def test_invalid_arguments_are_rejected_before_launch(call, needle):
     lib = _lib.load()
@@ -71,6 +75,17 @@ def test_invalid_arguments_are_rejected_before_launch(call, needle):
     assert needle in msg, msg
     with pytest.raises(RuntimeError):
         _lib.check(rc, "test")
+
+
+def test_splitk_workspace_size_and_plan_without_a_gpu():
+    """Host-only helpers of the split-K GEMM: flags page + 2 x 128 KiB of fp32 half-tiles per 256 x 256 tile; a shape is only
+    planned as split-K on a device whose CUs hold the whole grid (none here)."""
+    lib = _lib.load()
+    assert lib.ll_gemm_splitk_workspace_bytes(4680, 1536) == 4096 + 19 * 6 * 2 * 8 * 16 * 64 * 4 * 4
+    assert lib.ll_gemm_splitk_workspace_bytes(4680, 1500) == 0 and lib.ll_gemm_splitk_workspace_bytes(0, 1536) == 0
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.ll_gemm_splitk_plan(4680, 1536, 8960, 0) == 0
 
 
 def test_ops_refuse_cpu_tensors():
