@@ -121,14 +121,19 @@ int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf1
  * epilogues, same arguments.  Taken when ll_gemm_splitk_plan(M, N, K, 0) == 1 (N % 256 == 0, K % 128 == 0, K >= 1024 and the
  * 2 x ceil(M / 256) x (N / 256) workgroups fit the device in one round) and workspace != NULL; otherwise it IS ll_gemm_bf16.
  * workspace: >= ll_gemm_splitk_workspace_bytes(M, N) bytes of 16-byte-aligned device memory, zeroed ONCE by the caller before its
- * first use (the kernel leaves its flags zero) and used by the launches of one stream at a time.  Results equal ll_gemm_bf16's up
- * to the order of the fp32 accumulation (two K-halves summed at the end); run to run they are bit-identical. */
+ * first use and used by the launches of one stream at a time.  Results equal ll_gemm_bf16's up to the order of the fp32
+ * accumulation (two K-halves summed at the end); run to run they are bit-identical.
+ * Fail-safe hand-off: the partner flags carry a per-launch epoch (stale words never match, nothing is reset) and the wait is
+ * bounded (50 ms of real time): a partner workgroup that never arrives leaves the launch's epoch in the workspace's error word
+ * and the kernel drains -- the output of that launch is invalid, the GPU is not hung.  ll_gemm_splitk_status (BLOCKING on
+ * `stream`) returns that word in *status (0 = every hand-off so far completed) and clears it. */
 int ll_gemm_bf16_splitk(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
                         int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod, int nmod,
                         int gate_idx, int rows_per_batch, int frame_len, void* workspace, long long workspace_bytes,
                         ll_stream stream);
 long long ll_gemm_splitk_workspace_bytes(int M, int N);
 int ll_gemm_splitk_plan(int M, int N, int K, int int8);
+int ll_gemm_splitk_status(void* workspace, unsigned* status, ll_stream stream);
 /* ... and of ll_gemm_w8a8 (int32 partial sums: the exchange is exact, the result equals ll_gemm_w8a8's bit for bit). */
 int ll_gemm_w8a8_splitk(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias, ll_bf16* out,
                         int M, int N, int K, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ll_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
     "ll_gemm_splitk_workspace_bytes": [_i, _i],
     "ll_gemm_splitk_plan": [_i, _i, _i, _i],
+    "ll_gemm_splitk_status": [_p, _p, _p],
     "ll_gemm_w8a8_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ll_gemm_bf16_qkv": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],

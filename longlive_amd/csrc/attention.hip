@@ -1014,6 +1014,7 @@ static int attn_sk_workgroups(int B, int Lq, int H, int nkeys, long long workspa
 }
 
 extern "C" long long ll_flash_attn_workspace_bytes(void) {
+  if (g_attn_sk_wgs < 0) return 0;                        // stream-K off (default): no workspace is read or written
   int w = g_attn_sk_wgs > 0 ? g_attn_sk_wgs : attn_num_cus();
   return (long long)w * 2 * SK_SLOT_FLOATS(8) * 4;
 }

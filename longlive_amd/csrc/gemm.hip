@@ -20,6 +20,7 @@
 //  a DMA-issue stagger between the two waves of a SIMD measured 0...-5% and were not kept.)
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 
 #include "gemm_common.h"
 
@@ -502,6 +503,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4(const char* __restrict_
 // bits from the unsplit kernels' single accumulation chain.
 #define V4SK_PART_FLOATS (8 * 16 * 64 * 4)      // per (tile, split): [wave][a][b'][lane][4]
 #define V4SK_FLAG_BYTES 4096
+#define V4SK_ERR_WORD (V4SK_FLAG_BYTES / 4 - 1)   // last word of the flag page: epoch of a launch whose hand-off timed out (0 = none)
+#define V4SK_POLL_TICKS 5000000ull             // 50 ms of s_memrealtime (100 MHz); a hand-off takes ~2 us
 
 template <bool L2, typename V>
 __device__ __forceinline__ void sk_store(float* p, V v) {      // f32x4 partial sums, or i32x4 (W8A8: exact integers)
@@ -512,7 +515,7 @@ __device__ __forceinline__ void sk_store(float* p, V v) {      // f32x4 partial 
 template <int EPI, bool I8, int SPLIT, bool L2>
 __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], float* __restrict__ part, unsigned* __restrict__ flags, int tile,
                                             bf16* __restrict__ Y, int M, int N, int ldo, int mw, int nw, int wave, int lane,
-                                            const EpiArgs& ea) {
+                                            const EpiArgs& ea, unsigned epoch) {
   constexpr int GIVE = SPLIT ^ 1;
   float* mine = part + ((size_t)tile * 2 + SPLIT) * V4SK_PART_FLOATS + ((size_t)wave * 16 * 64 + lane) * 4;
   float* theirs = part + ((size_t)tile * 2 + GIVE) * V4SK_PART_FLOATS + ((size_t)wave * 16 * 64 + lane) * 4;
@@ -523,14 +526,24 @@ __device__ __forceinline__ void v4sk_finish(typename Ty<I8>::acc (&acc)[4][8], f
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(flags + tile * 2 + SPLIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The flag carries THIS launch's epoch (a process-wide launch counter, never 0): a word left behind by an earlier or an
+    // aborted launch on the same workspace can never match, and nothing has to be reset.  The poll is bounded by the 100 MHz
+    // real-time counter: a partner that never arrives (it faulted, its process was killed, the grid was not co-resident after
+    // all) costs V4SK_POLL_TICKS, sets the workspace's error word and lets the kernel drain with a wrong tile instead of
+    // hanging the wave -- ll_gemm_splitk_status() reports it at the caller's next synchronisation point.
+    __hip_atomic_exchange(flags + tile * 2 + SPLIT, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned* pf = flags + tile * 2 + GIVE;
     unsigned v;
-    do {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pf) : "memory");
-      if (v == 0) __builtin_amdgcn_s_sleep(4);
-    } while (v == 0);
-    __hip_atomic_store(pf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch on this workspace
+      if (v == epoch) break;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > V4SK_POLL_TICKS) {
+        __hip_atomic_store(flags + V4SK_ERR_WORD, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
   }
   __syncthreads();
   typedef typename Ty<I8>::acc acc_t;
@@ -605,7 +618,8 @@ template <int EPI, bool I8, bool L2>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restrict__ X, const char* __restrict__ Wt,
                                                            bf16* __restrict__ Y, int M, int N, int nkh, size_t xrow_bytes,
                                                            size_t wrow_bytes, int ldo, int ntiles, int ntn,
-                                                           float* __restrict__ part, unsigned* __restrict__ flags, EpiArgs ea) {
+                                                           float* __restrict__ part, unsigned* __restrict__ flags, EpiArgs ea, unsigned epoch,
+                                                           int fault) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Ty<I8>::frag frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -617,6 +631,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restric
   const int q_ = ntiles >> 3, r_ = ntiles & 7;
   const int cnt = q_ + (xcd < r_ ? 1 : 0), start = xcd * q_ + (xcd < r_ ? xcd : r_);
   if (pair >= cnt) return;                                  // grid padding (whole workgroup, before any barrier)
+  if (fault && split == 1) return;                          // test hook (tuning key gemm_splitk_fault): a partner that never arrives
   const int tile = start + pair;
   const int mt_ = tile / ntn, nt_ = tile - mt_ * ntn;
   const int m0 = mt_ * V3_BM, n0 = nt_ * V3_BN;
@@ -666,8 +681,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_v4sk(const char* __restric
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (split == 0) v4sk_finish<EPI, I8, 0, L2>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
-  else v4sk_finish<EPI, I8, 1, L2>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea);
+  if (split == 0) v4sk_finish<EPI, I8, 0, L2>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea, epoch);
+  else v4sk_finish<EPI, I8, 1, L2>(acc, part, flags, tile, Y, M, N, ldo, m0 + wm * 128, n0 + wn * 64, wave, lane, ea, epoch);
 }
 #undef V4_LOAD_A
 #undef V4_LOAD_B
@@ -689,11 +704,18 @@ void ll_set_attn_sk_internal(int v);
 void ll_set_attn_pp_min_internal(int v);
 void ll_set_conv_halo_internal(int v);
 void ll_set_splitk_l2_internal(int v);
+void ll_set_splitk_fault_internal(int v);
 extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { g_gemm_variant = value; return LL_OK; }
   if (!strcmp(key, "gemm_group_m")) { g_gemm_group_m = value; return LL_OK; }
   if (!strcmp(key, "gemm_variant_wide")) { g_gemm_variant_wide = value; return LL_OK; }
-  if (!strcmp(key, "gemm_lds_epi")) { g_gemm_lds_epi = value; return LL_OK; }
+  if (!strcmp(key, "gemm_lds_epi")) {
+#ifndef LL_GEMM_DIAG      // bits 0x100 / 0x200 (K-loop staging / compute switched off: results invalid) exist for timing builds only
+    if (value < 0 || value > 2) { ll_set_error("ll_set_tuning: gemm_lds_epi=%d (0, 1 or 2; diagnostic bits need -DLL_GEMM_DIAG)", value); return LL_ERR_INVALID_ARG; }
+#endif
+    g_gemm_lds_epi = value;
+    return LL_OK;
+  }
   if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger = value; return LL_OK; }
   if (!strcmp(key, "gemm_ws")) { g_gemm_ws = value; return LL_OK; }
   if (!strcmp(key, "gemm_ws_mask")) { g_gemm_ws_mask = value; return LL_OK; }
@@ -703,6 +725,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "attn_pp_min_keys")) { ll_set_attn_pp_min_internal(value); return LL_OK; }
   if (!strcmp(key, "conv_halo")) { ll_set_conv_halo_internal(value); return LL_OK; }
   if (!strcmp(key, "gemm_splitk_l2")) { ll_set_splitk_l2_internal(value); return LL_OK; }
+  if (!strcmp(key, "gemm_splitk_fault")) { ll_set_splitk_fault_internal(value); return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }
@@ -949,7 +972,8 @@ extern "C" int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b
 // Split-K form of ll_gemm_bf16 (gemm_kernel_v4sk): same arguments plus a workspace.  Taken when N is a multiple of 256, K a
 // multiple of 128 and the 2 x (M / 256) x (N / 256) workgroups fit the device in one round; every other shape runs ll_gemm_bf16's
 // kernels (the workspace is then unused).  workspace: >= ll_gemm_splitk_workspace_bytes(M, N) bytes, 16-byte aligned, ZEROED
-// once by the caller before its first use and afterwards owned by the launches of ONE stream (the kernel leaves its flags zero).
+// once by the caller before its first use (only the error word needs it: flags carry a per-launch epoch) and afterwards owned by
+// the launches of ONE stream.  ll_gemm_splitk_status() reports a timed-out hand-off.
 static int splitk_tiles(int M, int N) { return ((M + 255) / 256) * (N / 256); }
 static int device_cus() {
   static int cus[64];
@@ -970,6 +994,8 @@ __global__ void xcc_probe_kernel(unsigned* out) {
 static int g_gemm_splitk_l2 = 0;     // tuning key gemm_splitk_l2: 1 = exchange through the pair's L2 (plain stores / loads) when the
                                      // placement probe allows it; measured 146.8 vs 150.9 us alone, +0.1 % in the pipeline: off
 void ll_set_splitk_l2_internal(int v) { g_gemm_splitk_l2 = v; }
+static int g_gemm_splitk_fault = 0;  // tuning key gemm_splitk_fault (tests only): 1 = the second workgroup of every pair exits before publishing
+void ll_set_splitk_fault_internal(int v) { g_gemm_splitk_fault = v; }
 // 1 when blocks b and b + 8k of a launch run on one XCD on this device (probed once with 2048 single-wave blocks), else 0
 static int splitk_same_xcd() {
   static int cached[64];
@@ -993,6 +1019,12 @@ static int splitk_same_xcd() {
   return cached[dev] > 0 ? 1 : 0;
 }
 
+// Co-residency: the two workgroups of a pair wait for each other, so both must be resident at once.  The launcher guarantees
+// it for THIS launch only (grid <= CU count at one 128-KiB-LDS workgroup per CU); a co-running launch on another stream (the VAE
+// decoder's 132-KiB-LDS convolutions under overlap_decode, a second split-K FFN2 under overlap_context, another process) can hold
+// CUs, and progress then rests on the dispatcher handing freed CUs to the oldest pending workgroups -- observed, not promised.
+// That is why the hand-off is fail-safe rather than assumed: epoch-valued flags (a stale or foreign word never matches) and a
+// poll bounded by real time (V4SK_POLL_TICKS) that records the failure in the workspace instead of hanging the wave.
 static bool splitk_eligible(int M, int N, int kbytes) {      // kbytes = bytes of K per operand row (bf16: 2 K, int8: K)
   if (M <= 0 || N <= 0 || N % 256 != 0 || kbytes % 256 != 0 || kbytes < 2048) return false;
   const int tiles = splitk_tiles(M, N);
@@ -1004,6 +1036,24 @@ extern "C" long long ll_gemm_splitk_workspace_bytes(int M, int N) {
   return (long long)V4SK_FLAG_BYTES + (long long)splitk_tiles(M, N) * 2 * V4SK_PART_FLOATS * 4;
 }
 extern "C" int ll_gemm_splitk_plan(int M, int N, int K, int int8) { return splitk_eligible(M, N, int8 ? K : 2 * K) ? 1 : 0; }
+
+// Reads back the workspace's error word (BLOCKING: synchronises `stream`).  *status = 0: every hand-off of every launch on this
+// workspace so far completed; otherwise the epoch of a launch whose partner workgroup did not arrive within the poll budget --
+// that launch's output is invalid.  The word is cleared, so the workspace can be used again.
+extern "C" int ll_gemm_splitk_status(void* workspace, unsigned* status, ll_stream stream) {
+  LL_REQUIRE(workspace != nullptr && status != nullptr, "ll_gemm_splitk_status: needs a workspace and an output word");
+  unsigned* w = (unsigned*)workspace + V4SK_ERR_WORD;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(status, w, sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    ll_set_error("ll_gemm_splitk_status: read-back failed: %s", hipGetErrorString(hipGetLastError()));
+    return LL_ERR_LAUNCH;
+  }
+  if (*status != 0 && hipMemsetAsync(w, 0, sizeof(unsigned), s) != hipSuccess) {
+    ll_set_error("ll_gemm_splitk_status: could not clear the error word");
+    return LL_ERR_LAUNCH;
+  }
+  return LL_OK;
+}
 
 template <bool I8>
 static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out, int M, int N, int K, size_t xrow_bytes,
@@ -1022,6 +1072,9 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
   float* part = (float*)((char*)workspace + V4SK_FLAG_BYTES);
   const size_t lds = 2 * V3_STAGE;
   const bool l2 = g_gemm_splitk_l2 && splitk_same_xcd();
+  static std::atomic<unsigned> launch_counter{0};
+  unsigned epoch = launch_counter.fetch_add(1u, std::memory_order_relaxed) + 1u;
+  if (epoch == 0) epoch = launch_counter.fetch_add(1u, std::memory_order_relaxed) + 1u;      // 0 = "no flag"
 #define SK_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
     static bool ask = false;                                                                                           \
@@ -1032,10 +1085,10 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
     }                                                                                                                  \
     if (l2)                                                                                                            \
       hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8, true>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh, \
-                         xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea);                                    \
+                         xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea, epoch, g_gemm_splitk_fault);        \
     else                                                                                                               \
       hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8, false>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh, \
-                         xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea);                                    \
+                         xrow_bytes, wrow_bytes, ldo, tiles, ntn, part, flags, ea, epoch, g_gemm_splitk_fault);        \
   } while (0)
   switch (epilogue) {
     case LL_EPI_BIAS: SK_LAUNCH(LL_EPI_BIAS); break;

@@ -278,6 +278,26 @@ def splitk_workspace(device, M: int, N: int) -> torch.Tensor:
     return buf
 
 
+def splitk_check() -> None:
+    """BLOCKING: reads back the error word of every split-K workspace (ll_gemm_splitk_status) and raises if a hand-off of any
+    launch since the last check timed out (that launch's output is invalid).  Called where the host synchronises anyway: the end
+    of a pipeline's inference(), bench.py after its timed region, the tests."""
+    if not _splitk_ws:
+        return
+    import ctypes as C
+    lib = _lib.load()
+    bad = []
+    for key, buf in list(_splitk_ws.items()):
+        st = C.c_uint(0)
+        with torch.cuda.device(buf.device):
+            _lib.check(lib.ll_gemm_splitk_status(buf.data_ptr(), C.addressof(st), key[2] or None), "ll_gemm_splitk_status")
+        if st.value:
+            buf[:4096].zero_()                # flags carry epochs (stale words never match); start from a clean page anyway
+            bad.append((key, st.value))
+    if bad:
+        raise RuntimeError(f"split-K GEMM hand-off timed out (workspace, launch epoch): {bad}; the outputs of those launches are invalid")
+
+
 def gemm_qkv_v_insert(x, w, bias, cache_v, write_start: int, roped_offset: int, write_len: int, xq=None, tag: str = "gemm_qkv"):
     """The fused q|k|v projection x [B,L,K] @ w [3C,K]^T + bias with the V third inserted into cache_v [B,S,H,D] by the GEMM
     epilogue (token t -> slot write_start + t - roped_offset for 0 <= t - roped_offset < write_len).  Returns the [B,L,3C]
@@ -394,12 +414,15 @@ def linear_small(x, w, bias, act_in: int = 0, act_out: int = 0):
 _attn_ws = {}
 
 
-def attn_workspace(device) -> torch.Tensor:
-    """Scratch for ll_flash_attn's stream-K path (the ABI never allocates): one buffer per device, reused by every launch on
-    the stream (launches on one stream are ordered, and a launch reads only what it wrote itself)."""
+def attn_workspace(device) -> Optional[torch.Tensor]:
+    """Scratch for ll_flash_attn's stream-K path (the ABI never allocates).  None while stream-K is off (the default tuning:
+    ll_flash_attn_workspace_bytes() == 0), otherwise one buffer per (device, STREAM) -- two streams may run self-attention
+    concurrently (overlap_context) and a launch reads back what it wrote itself."""
     lib = _lib.load()
     need = int(lib.ll_flash_attn_workspace_bytes())
-    key = (device.type, device.index)
+    if need == 0:
+        return None
+    key = (device.type, device.index, int(_stream() or 0))
     buf = _attn_ws.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=device)
@@ -433,7 +456,8 @@ def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None, tag: 
         tag = tag or "flash_attn"
         t0 = timer.begin(tag)
     _lib.check(lib.ll_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, H, H * D, H * D,
-                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, ws.data_ptr(), ws.numel(), _stream()),
+                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, _ptr(ws), 0 if ws is None else ws.numel(),
+                                 _stream()),
                "ll_flash_attn")
     if timer is not None:
         timer.end(tag, t0, 4.0 * B * H * Lq * nkeys * D)     # algorithmic FLOPs: QK^T + PV

@@ -13,6 +13,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from .. import ops as _ops
 from ..wan_wrapper import WanDiffusionWrapper
 
 
@@ -258,6 +259,7 @@ class CausalInferencePipeline(nn.Module):
             video = self.vae.decode_to_pixel(output, use_cache=False)
             video = (video * 0.5 + 0.5).clamp(0, 1)
         prof.stop("vae")
+        _ops.splitk_check()           # the natural sync of a run: raises if a split-K hand-off timed out (invalid output)
         self.last_profile = prof.report(self.num_frame_per_block, switch_blocks=())
         if return_latents:
             return video, output

@@ -404,7 +404,7 @@ def test_qkv_projection_with_v_insert_is_bit_identical(ops, B, F, hp, wp, H, K, 
 def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
     """ll_gemm_bf16_splitk (256 x 256 tiles, K cut in two, halves exchanged through the workspace inside the kernel) against
     ll_gemm_bf16: same products, the fp32 sum split once more -> <= 1 bf16 ulp apart; 30 repeated launches are bit-identical
-    (a stale or torn hand-off would show up as a run-to-run difference) and leave the workspace flags at zero."""
+    (a stale or torn hand-off would show up as a run-to-run difference) and leave the workspace's error word at zero."""
     from longlive_amd import _lib
     x = hn("skx", (M, K)).to(DEV)
     w = (hn("skw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
@@ -425,9 +425,10 @@ def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
         again = ops.gemm(x, w, b, code, splitk=True, **kw)
         assert torch.equal(again, first)
     torch.cuda.synchronize()
+    ops.splitk_check()                                   # no hand-off timed out
     if eligible:
         ws = ops.splitk_workspace(x.device, M, N)
-        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+        assert int(ws[:4096].view(torch.int32)[-1]) == 0                  # error word clear; the flags hold launch epochs
         # a 1-ulp flip of bf16(acc + bias) (values up to ~4: ulp 2^-6) survives the gate / residual as an ABSOLUTE difference
         # while the sum itself may be small: absolute bound there, ulp bound for the plain epilogues
         fused = epi in ("gate", "res")
@@ -459,6 +460,41 @@ def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
         got = ops.gemm(xs[it & 1], w, b, ops.EPI_BIAS, splitk=True)
         assert torch.equal(got, want[it & 1])
     torch.cuda.synchronize()
+
+
+def test_gemm_splitk_handoff_is_fail_safe(ops):
+    """The hand-off never hangs and never trusts a stale word: (1) a flag page full of garbage (what an aborted launch or a foreign
+    writer could leave behind) changes nothing -- flags must equal THIS launch's epoch; (2) with the test hook that makes every
+    second workgroup exit before it publishes (a partner that never arrives), the launch still completes within the bounded poll,
+    ops.splitk_check() raises and names the workspace, and the next launch on the same workspace is correct again."""
+    import time
+    from longlive_amd import _lib
+    lib = _lib.load()
+    M, N, K = 4680, 1536, 8960
+    w = (hn("zw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("zb", (N,), 0.1).to(DEV)
+    x = hn("zx", (M, K)).to(DEV)
+    want = ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True)
+    ws = ops.splitk_workspace(x.device, M, N)
+    ws[:4092].view(torch.int32).fill_(0x5a5a5a5a)        # every flag word poisoned; the error word (last of the page) stays 0
+    for _ in range(3):
+        assert torch.equal(ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True), want)
+    ops.splitk_check()
+    try:
+        assert lib.ll_set_tuning(b"gemm_splitk_fault", 1) == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        broken = ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        lib.ll_set_tuning(b"gemm_splitk_fault", 0)
+    assert 0.02 < dt < 2.0, dt                           # the 50 ms poll budget, not a hang
+    with pytest.raises(RuntimeError, match="hand-off timed out"):
+        ops.splitk_check()
+    assert not torch.equal(broken, want)
+    assert torch.equal(ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True), want)
+    ops.splitk_check()
 
 
 def test_gemm_splitk_l2_exchange_matches(ops):
