@@ -17,7 +17,7 @@ time.  Two ways to get N replicas:
   * under torch.distributed.run (the driver's launch): RANK / LOCAL_RANK / WORLD_SIZE from the env; the start/stop barrier
     and the scalar MAX / SUM go through a gloo (CPU) process group -- nothing touches xGMI;
   * plain `python bench.py --gpus N` (WORLD_SIZE unset): this process starts N fresh children BEFORE it touches the GPU
-    (HIP_VISIBLE_DEVICES = r, seed + r), synchronises their timed regions over pipes (no process group at all) and prints
+    (HIP_VISIBLE_DEVICES = the r-th entry of the inherited mask, seed + r), synchronises their timed regions over pipes (no process group at all) and prints
     the one JSON line itself, with per-replica frames/s.  A child that fails => non-zero exit, no retry.
 
 The JSON line also carries
@@ -156,6 +156,112 @@ def side_workload(args):
     print(json.dumps(rec), flush=True)
 
 
+# ---- clock / power telemetry over the timed region ---------------------------------------------------------------------
+class Telemetry:
+    """Samples the card's hwmon files (power1_input [uW], freq1_input = sclk [Hz]) on a side thread every 20 ms while the timed
+    region runs, so that runs on different devices of a pool can be compared (devices differ by 8-12 % at identical code: the
+    board runs this pipeline at its package-power limit and the clock it can hold there differs per chip).  The card is the one
+    whose PCI address matches the torch device; failing that, the one that drew the most power during the region.  amdsmi (when it
+    initialises) adds the deltas of the throttle / power-limit residency accumulators of gpu_metrics.  Everything here is best
+    effort: a missing file or library leaves nulls, never fails the run."""
+
+    def __init__(self, device_index=0, period=0.02):
+        import glob
+        import threading
+        self.period, self._stop, self._thr = period, threading.Event(), None
+        self.cards = []
+        for pw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")):
+            d = os.path.dirname(pw)
+            card = pw.split("/")[4]
+            try:
+                pci = os.path.basename(os.path.realpath(os.path.join("/sys/class/drm", card, "device")))
+            except OSError:
+                pci = None
+            self.cards.append(dict(card=card, pci=pci, power=pw, freq=os.path.join(d, "freq1_input"), cap=os.path.join(d, "power1_cap"),
+                                   p=[], f=[]))
+        self.want_pci = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            self.want_pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        self._smi0 = self._smi(device_index)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def _smi(self, device_index):
+        try:
+            import amdsmi
+            if not getattr(Telemetry, "_smi_init", False):
+                amdsmi.amdsmi_init()
+                Telemetry._smi_init = True
+            hs = amdsmi.amdsmi_get_processor_handles()
+            h = hs[device_index] if device_index < len(hs) else hs[0]
+            if self.want_pci:
+                for x in hs:
+                    try:
+                        if amdsmi.amdsmi_get_gpu_device_bdf(x).lower() == self.want_pci.lower():
+                            h = x
+                    except Exception:
+                        pass
+            m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            return {k: v for k, v in m.items() if isinstance(v, (int, float)) and ("residency" in k or "throttle" in k or "acc" in k)}
+        except Exception as exc:
+            return {"error": repr(exc)[:120]}
+
+    def _loop(self):
+        while not self._stop.is_set():
+            for c in self.cards:
+                c["p"].append(self._read(c["power"]))
+                c["f"].append(self._read(c["freq"]))
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        self._thr = threading.Thread(target=self._loop, daemon=True)
+        self._thr.start()
+
+    def stop(self, device_index=0):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join()
+        out = {"sclk_mhz_avg": None, "sclk_mhz_min": None, "power_w_avg": None, "power_w_max": None, "power_cap_w": None,
+               "samples": 0, "source": None}
+        best = None
+        for c in self.cards:
+            p = [x for x in c["p"] if x is not None]
+            if not p:
+                continue
+            c["pavg"] = sum(p) / len(p)
+            if self.want_pci and c["pci"] and c["pci"].lower() == self.want_pci.lower():
+                best = c
+                break
+            if best is None or c["pavg"] > best["pavg"]:
+                best = c
+        if best is not None:
+            p = [x * 1e-6 for x in best["p"] if x is not None]
+            f = [x * 1e-6 for x in best["f"] if x is not None]
+            cap = self._read(best["cap"])
+            out.update(power_w_avg=sum(p) / len(p), power_w_max=max(p), samples=len(p), power_cap_w=None if cap is None else cap * 1e-6,
+                       source=f"hwmon {best['card']} ({best['pci']}), {1e3 * self.period:.0f} ms period, side thread over the timed region"
+                              + ("" if (self.want_pci and best["pci"] and best["pci"].lower() == self.want_pci.lower())
+                                 else "; card chosen by highest draw (no PCI match)"))
+            if f:
+                out.update(sclk_mhz_avg=sum(f) / len(f), sclk_mhz_min=min(f))
+        s1 = self._smi(device_index)
+        if self._smi0 and s1 and "error" not in self._smi0 and "error" not in s1:
+            out["gpu_metrics_delta"] = {k: s1[k] - self._smi0[k] for k in s1 if k in self._smi0 and s1[k] != self._smi0[k]}
+        elif s1 and "error" in s1:
+            out["gpu_metrics_delta"] = s1
+        return out
+
+
 # ---- replica synchronisation -------------------------------------------------------------------------------------------
 class NoSync:
     """One replica."""
@@ -249,7 +355,7 @@ def kernel_table(summary, quant, splitk=False):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
             name = _plan_text(lib.ll_gemm_plan, *gemm_shapes[tag], i8)
-            if tag == "gemm_f2" and splitk and lib.ll_gemm_splitk_plan(*gemm_shapes[tag], i8) == 1:
+            if tag == "gemm_f2" and splitk and not i8 and lib.ll_gemm_splitk_plan(*gemm_shapes[tag], i8) == 1:   # int8: _lin drops split-K
                 M_, N_, _ = gemm_shapes[tag]
                 name = (f"gemm_kernel_v4sk<{'i8' if i8 else 'bf16'}> tile 256x256 x split-K 2, {2 * ((M_ + 255) // 256) * (N_ // 256)} workgroups, "
                         "halves reduced in the epilogue")
@@ -275,7 +381,7 @@ def kernel_table(summary, quant, splitk=False):
     return rows
 
 
-def run_extras(gen, pipe_cls, interactive_cls, cfg, dev, budget_s=60.0):
+def run_extras(gen, pipe_cls, interactive_cls, cfg, dev, budget_s=75.0):
     """Side numbers after the timed region (never part of `value`), each with its own achieved / peak where one applies."""
     from longlive_amd import ops, synth
     t_start = time.perf_counter()
@@ -327,11 +433,12 @@ def run_extras(gen, pipe_cls, interactive_cls, cfg, dev, budget_s=60.0):
             I._recache_after_switch(noise, T, prompts[rep % 2])
             torch.cuda.synchronize()
             lat.append(1e3 * (time.perf_counter() - t0))
-        ms = min(lat[1:])
+        ms = min(lat[1:])                                    # MIN of the last 2 of 3 repetitions (the first one warms up); all in `all_ms`
         flop = 30 * 3772.5e9                                 # GEMM 1560.5 + attn 2153.1 + cross 58.9 GFLOP per layer
-        ex["prompt_switch_latency"] = {"value": ms, "unit": "ms", "higher_is_better": False,
+        ex["prompt_switch_latency"] = {"value": ms, "unit": "ms", "higher_is_better": False, "all_ms": lat,
                                        "what": "InteractiveCausalInferencePipeline._recache_after_switch: 12 frames in ONE forward, L = Lk = 18720, "
-                                               "global_sink=false (kv_only: the last layer stops after its K/V insert)",
+                                               "global_sink=false (kv_only: the last layer stops after its K/V insert); MIN of the last 2 of 3 "
+                                               "repetitions (all three in all_ms)",
                                        "achieved": flop / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit_rate": "TFLOP/s",
                                        "frac": flop / (ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS}
         del I
@@ -345,13 +452,46 @@ def run_extras(gen, pipe_cls, interactive_cls, cfg, dev, budget_s=60.0):
             rec, vae, lat = vae_bench.run(7, 2)
             del vae, lat
             rec2, vae, lat = vae_bench.run(7, 2)         # short timed region (4 latent frames): keep the better of two passes
+            passes = [rec["pixel_fps"], rec2["pixel_fps"]]
             rec = rec2 if rec2["pixel_fps"] > rec["pixel_fps"] else rec
             ex["vae_decode"] = {"value": rec["pixel_fps"], "unit": "pixel frames/s", "ms_per_latent_frame": rec["ms_per_latent_frame"],
                                 "achieved": rec["roofline"]["achieved"], "peak": rec["roofline"]["peak"], "unit_rate": "TFLOP/s",
-                                "frac": rec["roofline"]["frac"], "what": "streaming Wan-VAE decode 60x104 -> 480x832, all conv launches"}
+                                "frac": rec["roofline"]["frac"], "passes_pixel_fps": passes,
+                                "what": "streaming Wan-VAE decode 60x104 -> 480x832, all conv launches; BEST OF 2 short passes "
+                                        "(4 timed latent frames each; both values in passes_pixel_fps)"}
             del vae, lat
         except Exception as exc:
             ex["vae_decode"] = {"error": repr(exc)}
+    if left() > 25:
+        try:                                                 # live end-to-end rate: every block decoded while the next is generated
+            from longlive_amd.vae import WanVAEWrapper
+            vcfg = synth.VaeConfig()
+            vae = WanVAEWrapper(vcfg, device=dev, chunk=3)
+            vae.load_state_dict(synth.synth_vae_state_dict(vcfg, seed=5, device=dev))
+            prompt = {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1, device=dev)}
+            P = pipe_cls(_pipe_args(), dev, generator=gen, text_encoder=lambda text_prompts: prompt, vae=vae)
+            nb = 11                                          # 5 blocks fill the window (+ one of margin), 5 timed intervals
+            noise = synth.synth_noise(cfg, 3 * nb, seed=0, device=dev)
+            res = {}
+            for key, overlap in (("serial", False), ("overlap_decode", True)):
+                times = []
+                for _, px in P.stream_video(noise, ["p0"], overlap_decode=overlap):
+                    if overlap:
+                        px[0, -1, 0, 0, 0].item()            # wait for THIS block's pixels only (the next block keeps running)
+                    else:
+                        torch.cuda.synchronize()
+                    times.append(time.perf_counter())
+                torch.cuda.synchronize()
+                steady = [(b - a) * 1e3 for a, b in zip(times[5:-1], times[6:])]
+                res[key] = {"fps": 12e3 * len(steady) / sum(steady), "ms_per_block": sum(steady) / len(steady), "blocks_timed": len(steady)}
+            ex["e2e_live"] = {"value": res["overlap_decode"]["fps"], "unit": "pixel frames/s", "serial": res["serial"],
+                              "overlap_decode": res["overlap_decode"],
+                              "what": "CausalInferencePipeline.stream_video at steady state: DiT block + streaming VAE decode of that block to "
+                                      "480x832 pixels; value = overlap_decode=True (block i decoded on a second HIP stream while block i+1 is "
+                                      "generated, bit-identical pixels), `serial` = decode after each block on one stream; MEAN over the timed blocks"}
+            del P, vae, noise
+        except Exception as exc:
+            ex["e2e_live"] = {"error": repr(exc)}
     if left() > 25:
         try:
             import t5_bench
@@ -375,7 +515,7 @@ def run_replica(args, rank, world, local_rank, sync):
         sync.end_barrier()
         elapsed = time.perf_counter() - t0
         return dict(frames=args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed=elapsed, roofline=None, kernels=None,
-                    extras=None, cpu_baseline=None)
+                    extras=None, cpu_baseline=None, visible=os.environ.get("HIP_VISIBLE_DEVICES"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -415,10 +555,13 @@ def run_replica(args, rank, world, local_rank, sync):
     ktimer = None
     if not args.no_kernel_timer and rank == 0:
         ktimer = ops.KernelTimer(tags=("flash_attn_self",))
+    tele = Telemetry(local_rank) if rank == 0 else None
     torch.cuda.synchronize()
     sync.barrier()
     torch.cuda.synchronize()
     ops.timer = ktimer
+    if tele is not None:
+        tele.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         next(stream)
@@ -426,8 +569,11 @@ def run_replica(args, rank, world, local_rank, sync):
     sync.end_barrier()
     elapsed = time.perf_counter() - t0
     ops.timer = None
+    telemetry = tele.stop(local_rank) if tele is not None else None
+    ops.splitk_check()                                                 # raises if a split-K hand-off timed out (invalid output)
     res = dict(frames=args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed=elapsed, roofline=None, kernels=None, extras=None,
-               cpu_baseline=None, overlap_context=bool(pipe.overlap_context))
+               cpu_baseline=None, overlap_context=bool(pipe.overlap_context), telemetry=telemetry,
+               visible=os.environ.get("HIP_VISIBLE_DEVICES"))
     if rank != 0:
         return res
     if ktimer is not None and "flash_attn_self" in ktimer.records:
@@ -495,8 +641,10 @@ def final_record(args, world, per_replica, res0):
         "config": {"workload": WORKLOAD, "frames_per_step": 3 * PIXEL_FRAMES_PER_LATENT,
                    "ms_per_latent_frame": 1e3 * elapsed / args.steps / 3, "replicas": world,
                    "parallelism": f"replicas x{world} (no collective on the data path, no RCCL)",
-                   "per_replica_fps": [r["frames"] / r["elapsed"] for r in sorted(per_replica, key=lambda r: r["rank"])]},
+                   "per_replica_fps": [r["frames"] / r["elapsed"] for r in sorted(per_replica, key=lambda r: r["rank"])],
+                   "per_replica_visible_devices": [r.get("visible") for r in sorted(per_replica, key=lambda r: r["rank"])]},
         "roofline": res0.get("roofline"), "cpu_baseline": res0.get("cpu_baseline"),
+        "telemetry": res0.get("telemetry"),
     }
     if res0.get("kernels") is not None:
         out["kernels"] = res0["kernels"]
@@ -506,6 +654,26 @@ def final_record(args, world, per_replica, res0):
 
 
 # ---- launcher: `python bench.py --gpus N` without torchrun -------------------------------------------------------------
+def child_visibility(parent_env, r: int, ndev: int) -> dict:
+    """Device mask of replica r, translated THROUGH the parent's own mask: `ndev` was counted under the parent's visibility, so
+    replica r must get the r-th entry of the inherited HIP_VISIBLE_DEVICES (or CUDA_VISIBLE_DEVICES) list, not the bare index r --
+    with an allotment such as HIP_VISIBLE_DEVICES=4,5 the bare index would put the children on physical GPUs 0 and 1, outside the
+    allotted set.  ROCR_VISIBLE_DEVICES is left untouched: HIP indices are relative to it.  Both HIP_ and CUDA_VISIBLE_DEVICES are
+    set to the same single entry so that an inherited one cannot compose with the new one."""
+    mask = parent_env.get("HIP_VISIBLE_DEVICES")
+    if mask is None or mask.strip() == "":
+        mask = parent_env.get("CUDA_VISIBLE_DEVICES")
+    slot = r % max(1, ndev)
+    if mask is not None and mask.strip() != "":
+        entries = [e.strip() for e in mask.split(",") if e.strip() != ""]
+        if slot >= len(entries):
+            raise SystemExit(f"bench.py launcher: replica {r} needs entry {slot} of the inherited device mask {mask!r}")
+        dev = entries[slot]
+    else:
+        dev = str(slot)
+    return {"HIP_VISIBLE_DEVICES": dev, "CUDA_VISIBLE_DEVICES": dev}
+
+
 def launch_replicas(args, argv):
     """Starts N children before this process has touched the GPU (no torch.cuda call above this line in the parent), one
     device each, and acts as their rendezvous.  No retry: any child failure ends the run with a non-zero exit."""
@@ -518,9 +686,9 @@ def launch_replicas(args, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ)
-        env.update(LL_BENCH_CHILD="1", LL_BENCH_RANK=str(r), LL_BENCH_WORLD=str(n), HIP_VISIBLE_DEVICES=str(r % max(1, ndev)),
+        env.update(LL_BENCH_CHILD="1", LL_BENCH_RANK=str(r), LL_BENCH_WORLD=str(n),
                    HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        env.pop("ROCR_VISIBLE_DEVICES", None)
+        env.update(child_visibility(os.environ, r, ndev))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.PIPE,
                                       stdout=subprocess.PIPE, text=True, bufsize=1))
 
@@ -549,7 +717,7 @@ def launch_replicas(args, argv):
         p.stdin.close()
         if p.wait() != 0:
             fail(f"replica {r} exited with code {p.returncode}")
-    per = [dict(rank=r, frames=res["frames"], elapsed=res["elapsed"]) for r, res in enumerate(results)]
+    per = [dict(rank=r, frames=res["frames"], elapsed=res["elapsed"], visible=res.get("visible")) for r, res in enumerate(results)]
     print(json.dumps(final_record(args, n, per, results[0])), flush=True)
 
 

@@ -73,3 +73,25 @@ def test_failing_replica_fails_the_run():
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "exited" in out.stderr and "{\"metric\"" not in out.stdout
+
+
+def test_launcher_translates_ranks_through_the_inherited_device_mask():
+    """with an allotment like HIP_VISIBLE_DEVICES=2,3 the children must run on entries 2 and 3 of the physical
+    numbering (the r-th entry of the inherited mask), not on the bare ranks 0 and 1; ROCR_VISIBLE_DEVICES is passed through and an
+    inherited CUDA_VISIBLE_DEVICES cannot compose with the new value."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.child_visibility({"HIP_VISIBLE_DEVICES": "2,3"}, 1, 2) == {"HIP_VISIBLE_DEVICES": "3", "CUDA_VISIBLE_DEVICES": "3"}
+    assert bench.child_visibility({"CUDA_VISIBLE_DEVICES": "5, 7"}, 0, 2)["HIP_VISIBLE_DEVICES"] == "5"
+    assert bench.child_visibility({}, 3, 8)["HIP_VISIBLE_DEVICES"] == "3"
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-workload"],
+                         env=_env(HIP_VISIBLE_DEVICES="2,3", CUDA_VISIBLE_DEVICES="0,1,2,3", ROCR_VISIBLE_DEVICES="0,1,2,3,4,5"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["config"]["per_replica_visible_devices"] == ["2", "3"]
+    # one entry in the mask but two replicas asked for: refuse rather than run both on a device outside the allotment
+    out = subprocess.run([sys.executable, "-c",
+                          "import sys; sys.path.insert(0, %r); import bench; print(bench.child_visibility({'HIP_VISIBLE_DEVICES': '4'}, 1, 2))" % ROOT],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "inherited device mask" in out.stderr

@@ -1,0 +1,23 @@
+#!/bin/bash
+# In-pipeline counters: rocprofv3 --pmc passes over bench.py itself (the program directly after `--`, no tracing flags beside
+# --pmc), so that MFMA utilisation, wave-cycle shares and fabric traffic are stated for the regime the headline is measured in
+# (kernels running back to back inside the 30-layer forward, the clock the pipeline holds), next to the tools/kbench figures.
+# Run ON the GPU box:   bash tools/pmc_inpipe.sh <outdir>     then   python tools/pmc_inpipe_summary.py <outdir> --md ... --json ...
+set -u
+OUT=${1:-gpurun_out/pmc_inpipe}
+mkdir -p "$OUT"
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+ARGS="bench.py --steps 2 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer"
+pass() {
+  name=$1; shift
+  timeout -k 10 420 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1
+  rc=$?
+  if [ $rc -ge 124 ]; then echo "pass $name killed (rc $rc): stopping"; exit $rc; fi
+  if [ $rc -ne 0 ]; then echo "pass $name failed (rc $rc), skipped"; tail -3 "$OUT/$name.log"; else echo "pass $name ok: $(grep -o '"value": [0-9.]*' "$OUT/$name.log" | head -1)"; fi
+}
+pass trace --kernel-trace
+pass sq1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+pass tcc_rd --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum GRBM_GUI_ACTIVE
+pass tcc_wr --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum GRBM_GUI_ACTIVE
+echo "done: $OUT"
