@@ -641,6 +641,269 @@ __global__ __launch_bounds__(NW * 64, PP ? 1 : 2) void flash_attn_pipe_kernel(co
 }
 
 
+
+// Reductions over the four 16-lane rows of a wave (lanes i, i+16, i+32, i+48) on the VALU: v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half
+// of the second; with both operands = x each leaves the two values to combine in the same lane.  Hazard nops inside the
+// statements (VALU write -> v_permlane read: 2 wait states).
+__device__ __forceinline__ float xrow_max4(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  float y = fmaxf(a, b);
+  float c2 = y, d = y;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c2), "+v"(d));
+  return fmaxf(c2, d);
+}
+__device__ __forceinline__ float xrow_sum4(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  float y = a + b;
+  float c2 = y, d = y;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c2), "+v"(d));
+  return c2 + d;
+}
+
+// =================================================================================================================
+// flash_attn_pipe_kernel<8, 1>'s ping-pong loop on v_mfma_f32_16x16x32_bf16 (tuning key attn_mfma16 = 1).  Same workgroup
+// (8 waves x 32 query rows), same per-wave output tile, same LDS rings, same SM / MM cut, same barrier-shifted wave groups; only
+// the MFMA shape and what follows from it differ.  Why it exists: where the chip holds its clock down under load the clock it
+// holds depends on the MFMA shape (MI355X_MICROARCH.md DVFS give-back item 7: 16x16x32 loops delivered 1.12-1.15x the FLOP/s of
+// 32x32x16 loops at equal cycles per FLOP), so the shape is decided by wall time of the real loop on random data.
+//   lane = 16 g + i.   S^T = K Q^T per (16-key block kb, 16-query block qb): lane holds query 16 qb + i, keys 16 kb + 4 g + reg.
+//   A query's 64 scores are spread over the 4 lanes i, i+16, i+32, i+48: row max = in-lane max of 16 + v_permlane16_swap +
+//   v_permlane32_swap; the row SUM stays lane-partial through the loop (all four lanes share the running max, so the rescale
+//   factor is common) and is reduced once in the epilogue.
+//   P^T as the B operand of O^T += V^T P^T (k = 32): element j of lane group g <-> key 32 ks + 16 (j >> 2) + 4 g + (j & 3) =
+//   accumulator registers of key blocks 2 ks and 2 ks + 1, no lane movement.  V^T fragments by two ds_read_b64_tr_b16 per
+//   (16-d block, k-step) in that same key order.  A 32-lane half then reads key rows 4 apart in the same columns, which the
+//   32x32 kernel's swizzle would serve 2-way: V chunk c of key r sits at c ^ (((r & 3) << 2) | (((r >> 2) & 1) << 1)).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void flash_attn_pipe16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
+                                                                       const bf16* __restrict__ Vc, bf16* __restrict__ O,
+                                                                       int Lq, int ldq, int ldo, int ldk,
+                                                                       long long k_batch_stride, int kstart, int nkeys,
+                                                                       float c, int nqt, int xcd_placement) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 K stages][4 V stages] x 16 KiB
+  constexpr int KSTAGES = PIPE_KSTAGES + 1, VSTAGES = PIPE_VSTAGES + 1;
+  char* const ksm = smem;
+  char* const vsm = smem + KSTAGES * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z;
+  int nwg_ = gridDim.x, bid_ = blockIdx.x;
+  int qq_ = nwg_ >> 3, rr_ = nwg_ & 7, xcd_ = bid_ & 7;
+  int lid_ = bid_;
+  if (xcd_placement) {                                   // as flash_attn_pipe_kernel: head-major ranges per XCD
+    int start_ = 0, nbig_ = 0, nsmall_ = 0, mine_ = 0;
+#pragma unroll
+    for (int k_ = 0; k_ < 8; ++k_) {
+      bool big_ = ((k_ + 1) * rr_) / 8 > (k_ * rr_) / 8;
+      int id_ = big_ ? nbig_++ : rr_ + nsmall_++;
+      mine_ = id_ == xcd_ ? start_ : mine_;
+      start_ += big_ ? qq_ + 1 : qq_;
+    }
+    lid_ = mine_ + (bid_ >> 3);
+  }
+  const int head = lid_ / nqt, qtile = lid_ % nqt;
+  const int q0 = qtile * (NW * 32) + wave * 32;
+  const int nt = (nkeys + KT - 1) / KT;
+  const int last_valid = nkeys - (nt - 1) * KT;
+  const bf16* kh = Kc + (size_t)b * k_batch_stride + (size_t)kstart * ldk + head * 128;
+  const bf16* vh = Vc + (size_t)b * k_batch_stride + (size_t)kstart * ldk + head * 128;
+
+  // Q^T fragments (B operand): lane (i, g) holds Q[q0 + 16 qb + i][32 ks + 8 g .. +7]
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int qr = q0 + 16 * qb + li;
+    qr = qr < Lq ? qr : Lq - 1;
+    const bf16* qp = Q + ((size_t)b * Lq + qr) * ldq + head * 128 + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + 32 * ks);
+  }
+
+  constexpr int NDMA = 16 / NW;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  int dma_key[NDMA], dma_kch[NDMA], dma_vch[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    int key = 4 * (wave * NDMA + i) + (lane >> 4), pos = lane & 15;
+    dma_key[i] = key;
+    dma_kch[i] = (pos ^ (key & 15)) * 16;
+    dma_vch[i] = (pos ^ (((key & 3) << 2) | (((key >> 2) & 1) << 1))) * 16;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define P16_DMA(T, KS, VS)                                                                       \
+  {                                                                                              \
+    int t_ = (T) < nt ? (T) : nt - 1;                                                            \
+    int valid_ = (t_ == nt - 1) ? last_valid : KT;                                               \
+    const char* kt_ = reinterpret_cast<const char*>(kh) + (size_t)t_ * KT * ldk * 2;            \
+    const char* vt_ = reinterpret_cast<const char*>(vh) + (size_t)t_ * KT * ldk * 2;            \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDMA; ++i_) {                                        \
+      int key_ = dma_key[i_] < valid_ ? dma_key[i_] : valid_ - 1;                                \
+      unsigned row_ = (unsigned)key_ * (unsigned)ldk * 2u;                                       \
+      int j_ = wave_u * NDMA + i_;                                                               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kt_ + row_ + dma_kch[i_]), (lptr_t)(ksm + (KS) * TILE_B + j_ * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_ + row_ + dma_vch[i_]), (lptr_t)(vsm + (VS) * TILE_B + j_ * 1024), 16, 0, 0); \
+    }                                                                                            \
+  }
+
+  // K A-fragment: key = 16 kb + i, 16-byte chunk 4 ks + g at position chunk ^ (key & 15)            (+ 4096 kb)
+  int k_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_off[ks] = li * 256 + (((4 * ks + g) ^ li) << 4);
+  // V tr-read: lane supplies row (key) K0 + 4 g + q, columns 16 db + 4 p .. +3  (q = i >> 2, p = i & 3)      (+ 256 K0)
+  const int tq = li >> 2, tp = li & 3;
+  int v_off[8];
+#pragma unroll
+  for (int db = 0; db < 8; ++db) {
+    int chunk = 2 * db + (tp >> 1);
+    v_off[db] = (4 * g + tq) * 256 + ((chunk ^ ((tq << 2) | ((g & 1) << 1))) << 4) + (tp & 1) * 8;
+  }
+
+  f32x4 o[2][8];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  P16_DMA(0, 0, 0);
+  P16_DMA(1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 s_cur[2][4];
+#define P16_QK(KN)                                                                               \
+  {                                                                                              \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) s_cur[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};  \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                             \
+    _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                           \
+      bf16x8 kf = *reinterpret_cast<const bf16x8*>((KN) + k_off[ks] + kb * 4096);                \
+      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                           \
+        s_cur[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ks], s_cur[qb][kb], 0, 0, 0); \
+    }                                                                                            \
+  }
+  P16_QK(ksm);
+  __syncthreads();   // K stage 0 is overwritten by iteration 0's staging
+
+  uint4 pw[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) pw[qb][k2] = make_uint4(0, 0, 0, 0);
+  typedef __attribute__((ext_vector_type(8))) short p16_s16x8;
+  // SM(t): softmax of S(t) -> P(t); VALU + transcendental only
+#define P16_SM(T)                                                                                \
+  {                                                                                              \
+    if ((T) == nt - 1 && last_valid < KT) {                                                      \
+      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                           \
+      _Pragma("unroll") for (int kb = 0; kb < 4; ++kb)                                           \
+      _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_)                                           \
+        if (16 * kb + 4 * g + r_ >= last_valid) s_cur[qb][kb][r_] = -INFINITY;                   \
+    }                                                                                            \
+    float alpha[2];                                                                              \
+    bool moved = false;                                                                          \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                           \
+      float mx = s_cur[qb][0][0];                                                                \
+      _Pragma("unroll") for (int kb = 0; kb < 4; ++kb)                                           \
+      _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) mx = fmaxf(mx, s_cur[qb][kb][r_]);        \
+      mx = xrow_max4(mx);                                                                        \
+      float m_new = fmaxf(m_run[qb], mx);                                                        \
+      alpha[qb] = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);                               \
+      moved = moved || (m_new != m_run[qb]);                                                     \
+      m_run[qb] = m_new;                                                                         \
+      float mc = m_new * c;                                                                      \
+      float rs = 0.f;                                                                            \
+      _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                         \
+        float p_[8];                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                          \
+          p_[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[qb][2 * k2 + (j >> 2)][j & 3], c, -mc)); \
+          rs += p_[j];                                                                           \
+        }                                                                                        \
+        pw[qb][k2] = make_uint4(pack_bf16x2(p_[0], p_[1]), pack_bf16x2(p_[2], p_[3]), pack_bf16x2(p_[4], p_[5]), \
+                                pack_bf16x2(p_[6], p_[7]));                                      \
+      }                                                                                          \
+      l_run[qb] = l_run[qb] * alpha[qb] + rs;      /* lane-partial: the 4 lanes of a query share m, hence alpha */ \
+    }                                                                                            \
+    if (__any(moved)) {                                                                          \
+      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                           \
+      _Pragma("unroll") for (int db = 0; db < 8; ++db)                                           \
+      _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) o[qb][db][r_] *= alpha[qb];               \
+    }                                                                                            \
+  }
+  // MM: O^T += V(VS)^T P^T (32 MFMAs, 32 transposed reads), then S = K(KS) Q^T (32 MFMAs, 16 reads)
+#define P16_MM(VS, KS)                                                                           \
+  {                                                                                              \
+    const char* vc = vsm + (VS) * TILE_B;                                                        \
+    _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                             \
+    _Pragma("unroll") for (int db = 0; db < 8; ++db) {                                           \
+      const char* a0 = vc + v_off[db] + (32 * k2) * 256;                                         \
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));                   \
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 16 * 256));        \
+      p16_s16x8 vv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                    \
+      bf16x8 vf = __builtin_bit_cast(bf16x8, vv);                                                \
+      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)                                           \
+        o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[qb][k2]), o[qb][db], 0, 0, 0); \
+    }                                                                                            \
+    P16_QK(ksm + (KS) * TILE_B);                                                                 \
+    /* LDS reads ~8 MFMAs ahead: 8 transposed reads up front, then 2 per 2 MFMAs; K reads 1 per 2 MFMAs */ \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                           \
+    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); \
+  }
+  const int late = __builtin_amdgcn_readfirstlane(wave >= NW / 2);
+  const bool own_block = xcd_placement >= 0 && qtile * (NW * 32) + wave_u * 32 < Lq;   // opaque always-true for waves with rows (see pipe kernel)
+  if (late) __syncthreads();
+  int kq = 1, kd = 2, vq = 0, vd = 2;      // slots: K(t+1), K(t+2), V(t), V(t+2)
+  for (int t = 0; t < nt; ++t) {
+    P16_DMA(t + 2, kd, vd);
+    if (own_block) P16_SM(t);
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(1);
+    if (own_block) P16_MM(vq, kq);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    kq = kd;
+    kd = kd == KSTAGES - 1 ? 0 : kd + 1;
+    vq = vq == VSTAGES - 1 ? 0 : vq + 1;
+    vd = vd == VSTAGES - 1 ? 0 : vd + 1;
+  }
+  if (!late) __syncthreads();
+#undef P16_DMA
+#undef P16_QK
+#undef P16_SM
+#undef P16_MM
+
+  // epilogue: lane holds O^T[d = 16 db + 4 g + (0..3)][query 16 qb + i].  v_permlane16_swap of the packed words of db = k (vdst)
+  // and k + 1 (src) gives every lane 16 contiguous bytes: d = 16 (k + (g & 1)) + 8 (g >> 1) .. +7.
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = xrow_sum4(l_run[qb]);
+    float inv = 1.0f / l;
+    const int qr = q0 + 16 * qb + li;
+    const int qc = qr < Lq ? qr : Lq - 1;
+    bf16* orow = O + ((size_t)b * Lq + qc) * ldo + head * 128;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      unsigned ax = pack_bf16x2(o[qb][k][0] * inv, o[qb][k][1] * inv), ay = pack_bf16x2(o[qb][k][2] * inv, o[qb][k][3] * inv);
+      unsigned bx = pack_bf16x2(o[qb][k + 1][0] * inv, o[qb][k + 1][1] * inv), by = pack_bf16x2(o[qb][k + 1][2] * inv, o[qb][k + 1][3] * inv);
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+      asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+      if (qr < Lq) *reinterpret_cast<uint4*>(orow + 16 * (k + (g & 1)) + 8 * (g >> 1)) = make_uint4(ax, ay, bx, by);
+    }
+  }
+}
+
 // =================================================================================================================
 // Stream-K form of the ping-pong kernel: the (batch, head, 256-row q-tile) x key-tile work of a launch is cut into W equal
 // CONTIGUOUS ranges of 64-key tile units, one per workgroup, W = number of CUs.
@@ -952,6 +1215,8 @@ static int g_attn_variant = LL_ATTN_VARIANT_DEFAULT;   // 0: simple kernel, 1: s
 static int g_attn_pp_min_keys = 16 * KT;   // key ranges at least this long run the ping-pong loop (cross-attention's 512 keys: one-barrier loop)
 void ll_set_attn_pp_min_internal(int v) { g_attn_pp_min_keys = v; }
 static int g_attn_xcd = 1;
+static int g_attn_mfma16 = 0;     // tuning key attn_mfma16: 1 = the ping-pong loop on v_mfma_f32_16x16x32_bf16 (flash_attn_pipe16_kernel)
+void ll_set_attn_mfma16_internal(int v) { g_attn_mfma16 = v; }
 // stream-K: -1 = off (DEFAULT), 0 = auto (one workgroup per CU when it shortens the walk), N > 0 = force N workgroups.
 // Off by default because it LOSES on this chip although it removes the idle CUs: interleaved A/B of bench.py on one device,
 // steady-state self-attention 532 us (228 workgroups x 293 tiles) vs 589 us (256 x 261 tiles + combine), 73.4 vs 69.8 frames/s
@@ -972,11 +1237,17 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
                               (int)((PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B));
     (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
+    (void)hipFuncSetAttribute((const void*)flash_attn_pipe16_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
     attr = true;
   }
   int nqt = (Lq + NW * 32 - 1) / (NW * 32);
   dim3 grid(nqt * H, 1, B), block(NW * 64);
-  if (g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys)   // short ranges (cross-attention, 512 keys): the one-barrier loop is faster
+  if (g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys && g_attn_mfma16)
+    hipLaunchKernelGGL((flash_attn_pipe16_kernel<NW>), grid, block, (PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B,
+                       (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
+                       k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
+  else if (g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys)   // short ranges (cross-attention, 512 keys): the one-barrier loop is faster
     hipLaunchKernelGGL((flash_attn_pipe_kernel<NW, 1>), grid, block, (PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B,
                        (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
                        k_batch_stride, kstart, nkeys, c, nqt, g_attn_xcd);
@@ -1032,6 +1303,9 @@ extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_l
     if (W > 0)
       snprintf(out, (size_t)cap, "flash_attn_sk_kernel<8> (ping-pong wave groups, stream-K), %d workgroups x %lld key tiles + "
                "flash_attn_sk_combine_kernel<8>", W, ((long long)nqt * H * B * ((n0 + KT - 1) / KT) + W - 1) / W);
+    else if (pp && g_attn_mfma16)
+      snprintf(out, (size_t)cap, "flash_attn_pipe16_kernel<8> (ping-pong wave groups, MFMA 16x16x32), %d workgroups of 256 query rows%s",
+               nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
     else
       snprintf(out, (size_t)cap, "flash_attn_pipe_kernel<8, %d> (%s), %d workgroups of 256 query rows%s", pp ? 1 : 0,
                pp ? "ping-pong wave groups" : "one-barrier loop", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");

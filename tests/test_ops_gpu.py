@@ -250,6 +250,47 @@ def test_flash_attn_online_softmax_rescale(ops):
     assert (got - exact).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("B,Lq,H,Sk,seg", [
+    (2, 300, 3, 1500, (0, 1437)),         # batch 2, ragged last key tile, padded waves in the last q-tile
+    (1, 64, 1, 1024, (0, 1024)),          # exactly at the ping-pong threshold, all but two waves padding
+    (1, 257, 2, 2000, (37, 1100)),        # key range that does not start at slot 0
+    (1, 520, 12, 1300, (0, 1300)),        # real head count, 3 q-tiles
+])
+def test_flash_attn_mfma16_variant(ops, B, Lq, H, Sk, seg):
+    """The ping-pong loop on v_mfma_f32_16x16x32_bf16 (tuning key attn_mfma16): same bar against fp64
+    as the shipped kernel, and within two kernels' rounding of it element by element."""
+    q = hn("aq", (B, Lq, H, 128))
+    k = hn("ak", (B, Sk, H, 128))
+    v = hn("av", (B, Sk, H, 128), 0.7)
+    exact = R.attention_exact(q, k[:, seg[0]:seg[1]], v[:, seg[0]:seg[1]])
+    base = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
+    try:
+        _set_tuning("attn_mfma16", 1)
+        got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
+    finally:
+        _set_tuning("attn_mfma16", 0)
+    err, berr = (got.double() - exact).abs().max().item(), (base.double() - exact).abs().max().item()
+    assert err < 1.2e-2 and rel_l2(got, exact) < 6e-3, (err, berr, rel_l2(got, exact))
+    assert (got.float() - base.float()).abs().max().item() < 8e-3
+
+
+def test_flash_attn_mfma16_variant_rescale(ops):
+    """Late and early running-max jumps (spiked keys in the last and the first tile of a 32-tile range) through the 16x16x32 loop:
+    its running max is shared by the four lanes of a query and its row sum stays lane-partial until the epilogue."""
+    B, Lq, H, Sk = 1, 64, 1, 2048
+    q, k, v = hn("sq", (B, Lq, H, 128)), hn("sk", (B, Sk, H, 128)), hn("sv", (B, Sk, H, 128))
+    k[0, 2040, 0] = (q[0, 5, 0].float() * 3).to(bf)
+    k[0, 3, 0] = (q[0, 9, 0].float() * 3).to(bf)
+    k[0, 1000, 0] = (q[0, 37, 0].float() * 3).to(bf)     # a query of the second 16-row block, mid-range
+    exact = R.attention_exact(q, k, v)
+    try:
+        _set_tuning("attn_mfma16", 1)
+        got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [(0, Sk)]).cpu().double()
+    finally:
+        _set_tuning("attn_mfma16", 0)
+    assert (got - exact).abs().max().item() < 2e-2
+
+
 def test_patchify_unpatchify_x0_add_noise(ops):
     cfg = synth.toy_config()
     B, F, Cc, H, W = 2, 3, 16, 8, 12
