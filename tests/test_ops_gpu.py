@@ -514,7 +514,7 @@ def test_gemm_splitk_handoff_is_fail_safe(ops):
     M, N, K = 4680, 1536, 8960
     w = (hn("zw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
     b = hn("zb", (N,), 0.1).to(DEV)
-    x = hn("zx", (M, K)).to(DEV)
+    x, x2 = hn("zx", (M, K)).to(DEV), hn("zx2", (M, K)).to(DEV)
     want = ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True)
     ws = ops.splitk_workspace(x.device, M, N)
     ws[:4092].view(torch.int32).fill_(0x5a5a5a5a)        # every flag word poisoned; the error word (last of the page) stays 0
@@ -525,7 +525,7 @@ def test_gemm_splitk_handoff_is_fail_safe(ops):
         assert lib.ll_set_tuning(b"gemm_splitk_fault", 1) == 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        broken = ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True)
+        broken = ops.gemm(x2, w, b, ops.EPI_BIAS, splitk=True)     # other input: the stale partner halves in the workspace are x's
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     finally:
@@ -533,7 +533,7 @@ def test_gemm_splitk_handoff_is_fail_safe(ops):
     assert 0.02 < dt < 2.0, dt                           # the 50 ms poll budget, not a hang
     with pytest.raises(RuntimeError, match="hand-off timed out"):
         ops.splitk_check()
-    assert not torch.equal(broken, want)
+    assert not torch.equal(broken, ops.gemm(x2, w, b, ops.EPI_BIAS))
     assert torch.equal(ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True), want)
     ops.splitk_check()
 

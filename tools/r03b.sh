@@ -1,6 +1,6 @@
 set -u
 O=gpurun_out/r03b; mkdir -p $O
-python -m pytest tests/test_ops_gpu.py tests/test_abi.py "tests/test_shipped_sizes_gpu.py::test_flash_attn_production_grids" -m gpu -x -q > $O/tests.log 2>&1; rc=$?; tail -3 $O/tests.log; [ $rc -eq 0 ] || exit $rc
+python -m pytest tests/test_ops_gpu.py::test_gemm_splitk_handoff_is_fail_safe tests/test_ops_gpu.py::test_gemm_splitk_l2_exchange_matches tests/test_ops_gpu.py::test_gemm_w8a8_splitk_is_exact "tests/test_shipped_sizes_gpu.py::test_flash_attn_production_grids" -m gpu -x -q > $O/tests.log 2>&1; rc=$?; tail -3 $O/tests.log; [ $rc -eq 0 ] || exit $rc
 B="python bench.py --steps 10 --warmup 4 --no-extras --no-cpu-baseline"
 for r in 1 2; do
   $B > $O/ab_base_$r.json 2>> $O/ab.err || exit 1
