@@ -1215,6 +1215,14 @@ static int g_attn_variant = LL_ATTN_VARIANT_DEFAULT;   // 0: simple kernel, 1: s
 static int g_attn_pp_min_keys = 16 * KT;   // key ranges at least this long run the ping-pong loop (cross-attention's 512 keys: one-barrier loop)
 void ll_set_attn_pp_min_internal(int v) { g_attn_pp_min_keys = v; }
 static int g_attn_xcd = 1;
+static int g_attn_asm = 0;        // tuning key attn_asm: 1 / 2 = long contiguous key ranges run flash_attn_asm_kernel (attention_asm.hip: 4 waves x 64
+                                  // rows, one wave per SIMD, generated hand-scheduled body; 1: buffer_load..lds staging, 2: global_load_lds staging)
+void ll_set_attn_asm_internal(int v) { g_attn_asm = v; }
+int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk,
+                          long long k_batch_stride, int kstart, int nkeys, float c, int xcd, int form, hipStream_t stream);
+static bool attn_asm_eligible(int nkeys, int ldk) {
+  return g_attn_asm && g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys && (long long)nkeys * ldk * 2 < 0x7fffffffLL;
+}
 static int g_attn_mfma16 = 0;     // tuning key attn_mfma16: 1 = the ping-pong loop on v_mfma_f32_16x16x32_bf16 (flash_attn_pipe16_kernel)
 void ll_set_attn_mfma16_internal(int v) { g_attn_mfma16 = v; }
 // stream-K: -1 = off (DEFAULT), 0 = auto (one workgroup per CU when it shortens the walk), N > 0 = force N workgroups.
@@ -1243,6 +1251,9 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
   }
   int nqt = (Lq + NW * 32 - 1) / (NW * 32);
   dim3 grid(nqt * H, 1, B), block(NW * 64);
+  if (attn_asm_eligible(nkeys, ldk))
+    return flash_attn_asm_launch((const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, B, Lq, H, ldq, ldo, ldk, k_batch_stride,
+                                 kstart, nkeys, c, g_attn_xcd, g_attn_asm, (hipStream_t)stream);
   if (g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys && g_attn_mfma16)
     hipLaunchKernelGGL((flash_attn_pipe16_kernel<NW>), grid, block, (PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B,
                        (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)out, Lq, ldq, ldo, ldk,
@@ -1303,6 +1314,9 @@ extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_l
     if (W > 0)
       snprintf(out, (size_t)cap, "flash_attn_sk_kernel<8> (ping-pong wave groups, stream-K), %d workgroups x %lld key tiles + "
                "flash_attn_sk_combine_kernel<8>", W, ((long long)nqt * H * B * ((n0 + KT - 1) / KT) + W - 1) / W);
+    else if (attn_asm_eligible(n0, H * 128))
+      snprintf(out, (size_t)cap, "%s (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups of 256 query rows%s",
+               g_attn_asm == 2 ? "flash_attn_asm_g_kernel" : "flash_attn_asm_kernel", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
     else if (pp && g_attn_mfma16)
       snprintf(out, (size_t)cap, "flash_attn_pipe16_kernel<8> (ping-pong wave groups, MFMA 16x16x32), %d workgroups of 256 query rows%s",
                nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");

@@ -1,0 +1,119 @@
+"""The generated self-attention kernel (longlive_amd/csrc/gen/attn_asm_gen.py) executed on the CPU by tools/gfx950_emu.py --
+the text that is assembled into the library, one workgroup, against an fp64 attention.  Both completion models of the emulator
+must pass: `lazy` (a memory operation completes only when an s_waitcnt retires it: missing / under-counted waits show as NaN) and
+`eager` (it completes at issue: a ring slot overwritten too early shows as wrong scores).  Also: the hazard linter is clean and the
+text assembles for gfx950."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "longlive_amd", "csrc", "gen"))
+
+import attn_asm_gen as G          # noqa: E402
+import gfx950_emu as E            # noqa: E402
+
+
+@pytest.fixture(scope="module", params=["buffer", "global"])
+def kernel_text(request):
+    """both staging forms: buffer_load ... lds through a shrinking descriptor, and global_load_lds with clamped tiles / rows"""
+    return G.generate(request.param, "LL" + request.param[0].upper())
+
+
+def bf16_bits(x):
+    return E.bf16_round(np.asarray(x, dtype=np.float32)).astype(np.uint16)
+
+
+def bf16_val(bits):
+    return E.bf16_to_f32(np.asarray(bits, dtype=np.uint32))
+
+
+def run_case(text, mode, rows_valid, nkeys, seed=0, spikes=(), nheads=2, head=1, kstart=3):
+    """One workgroup: 256 query-row slots of which rows_valid exist, keys [kstart, kstart + nkeys) of a cache with nheads heads."""
+    rng = np.random.default_rng(seed)
+    D = 128
+    ldq = ldo = ldk = nheads * D
+    nq = rows_valid
+    q = rng.standard_normal((nq, nheads, D)).astype(np.float32)
+    cache_rows = kstart + nkeys                      # the cache ENDS at the last key: anything past it is out of bounds
+    k = rng.standard_normal((cache_rows, nheads, D)).astype(np.float32)
+    v = (0.7 * rng.standard_normal((cache_rows, nheads, D))).astype(np.float32)
+    for (qi, ki, amp) in spikes:
+        k[kstart + ki, head] = amp * q[qi, head]
+    qb_, kb_, vb_ = bf16_bits(q), bf16_bits(k), bf16_bits(v)
+    mem = E.Memory()
+    aq, ak, av = mem.alloc(qb_), mem.alloc(kb_), mem.alloc(vb_)
+    ao = mem.alloc(np.full((nq, nheads, D), 0x7FC0, dtype=np.uint16))
+    m = E.Machine(text, mem, 4, mode=mode)
+    scale = 1.0 / math.sqrt(D)
+    c = np.float32(scale * 1.4426950408889634)
+    nt = (nkeys + 63) // 64
+    lastv = nkeys - 64 * (nt - 1)
+    kbase = ak + (kstart * ldk + head * D) * 2
+    vbase = av + (kstart * ldk + head * D) * 2
+    for wv in m.waves:
+        s = wv.s
+        def put64(i, val):
+            s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
+        put64(G.S_Q, aq + head * D * 2)
+        put64(G.S_O, ao + head * D * 2)
+        put64(G.S_K, kbase)
+        put64(G.S_V, vbase)
+        s[G.S_LDQ], s[G.S_LDO], s[G.S_LDK] = ldq * 2, ldo * 2, ldk * 2
+        s[G.S_ROWS], s[G.S_NT], s[G.S_LASTV] = rows_valid, nt, lastv
+        s[G.S_C] = int(E.f2u(c))
+        s[G.S_NREC] = (nkeys - 1) * ldk * 2 + D * 2
+        wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
+        wv.v[1:] = 0x7FC0BEEF                           # uninitialised registers are NaN poison
+        wv.a[:] = 0x7FC0BEEF
+    steps = m.run()
+    out = bf16_val(mem.get(ao).view(np.uint16).reshape(nq, nheads, D)[:, head])
+    qf, kf, vf = bf16_val(qb_[:, head]).astype(np.float64), bf16_val(kb_[kstart:, head]).astype(np.float64), bf16_val(vb_[kstart:, head]).astype(np.float64)
+    sc = (qf @ kf.T) * scale
+    p = np.exp(sc - sc.max(axis=1, keepdims=True))
+    ref = (p / p.sum(axis=1, keepdims=True)) @ vf
+    other = mem.get(ao).view(np.uint16).reshape(nq, nheads, D)[:, 1 - head]
+    assert (other == 0x7FC0).all(), "the kernel wrote outside its head's columns"
+    return out.astype(np.float64), ref, steps, m
+
+
+def test_generated_text_is_lint_clean_and_assembles(kernel_text, tmp_path):
+    assert G.lint(kernel_text) == []
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm assembler here")
+    src = tmp_path / "k.s"
+    src.write_text('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n.text\nkernel:\n' + kernel_text)
+    r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "k.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]
+
+
+@pytest.mark.parametrize("mode", ["lazy", "eager"])
+def test_full_block_ragged_keys(kernel_text, mode):
+    """256 valid rows, 7 key tiles the last of which holds 20 keys; the cache ends at the last key (staging past it must not
+    fault and must not leak into the result)."""
+    out, ref, steps, m = run_case(kernel_text, mode, rows_valid=256, nkeys=6 * 64 + 20)
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < 1.2e-2, err
+
+
+def test_padded_rows_and_idle_waves(kernel_text):
+    """72 valid rows (the last q-tile of Lq = 4680): wave 1 has 8 valid rows, waves 2 and 3 only stage and synchronise."""
+    out, ref, steps, m = run_case(kernel_text, "lazy", rows_valid=72, nkeys=5 * 64, seed=3)
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < 1.2e-2, err
+
+
+def test_rescale_path_is_taken_and_exact(kernel_text):
+    """Spiked keys far above the running reference (late, early and mid-range; both q-blocks of a wave): the lazy-max slow path
+    (O, l, the -m tile and the pending score tile rescaled once, after the pending P.V) must give the fp64 answer."""
+    spikes = [(5, 6 * 64 + 10, 3.0), (9, 3, 3.0), (40, 200, 2.5), (200, 130, 3.0)]
+    out, ref, steps, m = run_case(kernel_text, "lazy", rows_valid=256, nkeys=7 * 64, seed=5, spikes=spikes)
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < 2e-2, err

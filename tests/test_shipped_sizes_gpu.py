@@ -61,6 +61,11 @@ def test_flash_attn_production_grids(Lq):
         _tuning("attn_mfma16", 1)              # opt-in: the same ping-pong loop on v_mfma_f32_16x16x32_bf16
         m16 = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_mfma16", 0)
+        asm = {}
+        for form in (1, 2):                    # opt-in: the generated one-wave-per-SIMD kernel, both staging forms
+            _tuning("attn_asm", form)
+            asm[form] = ops.flash_attn(q, k, v, [(0, Lk)])
+        _tuning("attn_asm", 0)
         _tuning("attn_variant", 0)             # plain kernel: grid (q-tile, head, batch), no remap, no pipelining
         plain = ops.flash_attn(q, k, v, [(0, Lk)])
     finally:
@@ -68,12 +73,15 @@ def test_flash_attn_production_grids(Lq):
         _tuning("attn_variant", 2)
         _tuning("attn_sk_wgs", -1)
         _tuning("attn_mfma16", 0)
+        _tuning("attn_asm", 0)
     assert torch.equal(got, got0) and torch.equal(sk, sk0), "XCD-aware workgroup placement must not change a single bit"
     # every element: a wrong (head, q-tile) mapping or a dropped key tile is an O(1) error, far above two kernels' rounding
     d = (got.float() - plain.float()).abs()
     assert d.max().item() < 8e-3, d.max().item()
     assert (sk.float() - plain.float()).abs().max().item() < 8e-3
     assert (m16.float() - plain.float()).abs().max().item() < 8e-3
+    for form in (1, 2):
+        assert (asm[form].float() - plain.float()).abs().max().item() < 8e-3, form
     # sampled rows, exact: two rows of every (head, 256-row q-tile) workgroup, in different waves / lane halves; plus the
     # first and last rows
     nqt = (Lq + 255) // 256

@@ -436,6 +436,9 @@ class Machine:
     def i_s_cselect_b32(self, w, i):
         self.ws(w, i.ops[0], self.rs(w, i.ops[1]) if w.scc else self.rs(w, i.ops[2]))
 
+    def i_s_cselect_b64(self, w, i):
+        self.ws(w, i.ops[0], self.rs(w, i.ops[1], 2) if w.scc else self.rs(w, i.ops[2], 2), 2)
+
     def i_s_cmp_eq_u32(self, w, i): w.scc = int(self.rs(w, i.ops[0]) == self.rs(w, i.ops[1]))
     def i_s_cmp_lg_u32(self, w, i): w.scc = int(self.rs(w, i.ops[0]) != self.rs(w, i.ops[1]))
     def i_s_cmp_eq_i32(self, w, i): w.scc = int(self.rs(w, i.ops[0]) == self.rs(w, i.ops[1]))
@@ -673,12 +676,10 @@ class Machine:
             self.wv(w, dst, np.full(64, POISON, dtype=np.uint32), d)
 
         def complete():
+            idx = addr[:, None] + np.arange(nbytes)[None, :]
+            words = np.ascontiguousarray(self.lds[idx]).view(np.uint32)          # [64][nd]
             for d in range(nd):
-                vals = np.zeros(64, dtype=np.uint32)
-                for l in range(64):
-                    o = int(addr[l]) + 4 * d
-                    vals[l] = int.from_bytes(self.lds[o:o + 4].tobytes(), "little")
-                self.wv(w, dst, vals, d)
+                self.wv(w, dst, words[:, d], d)
         self._issue(w, "lgkm", complete)
 
     def i_ds_read_b128(self, w, i): self._ds_read(w, i, 16)
@@ -695,13 +696,13 @@ class Machine:
             self.wv(w, dst, np.full(64, POISON, dtype=np.uint32), d)
 
         def complete():
+            lanes = np.arange(64)
+            g, li = lanes >> 4, lanes & 15
             out = np.zeros((64, 4), dtype=np.uint32)          # 4 x 16-bit elements per lane
-            for g in range(4):
-                for li in range(16):
-                    for q in range(4):
-                        src_lane = 16 * g + 4 * q + (li >> 2)
-                        o = int(addr[src_lane]) + 2 * (li & 3)
-                        out[16 * g + li, q] = int.from_bytes(self.lds[o:o + 2].tobytes(), "little")
+            for q in range(4):
+                src = 16 * g + 4 * q + (li >> 2)
+                o = addr[src] + 2 * (li & 3)
+                out[:, q] = self.lds[o].astype(np.uint32) | (self.lds[o + 1].astype(np.uint32) << 8)
             self.wv(w, dst, out[:, 0] | (out[:, 1] << 16), 0)
             self.wv(w, dst, out[:, 2] | (out[:, 3] << 16), 1)
         self._issue(w, "lgkm", complete)
@@ -785,10 +786,9 @@ class Machine:
         def complete():
             for l in range(64):
                 if valid is not None and not valid[l]:
-                    chunk = np.zeros(16, dtype=np.uint8)
+                    self.lds[base + 16 * l: base + 16 * l + 16] = 0
                 else:
-                    chunk = self.mem.read(int(addrs[l]), 16)
-                self.lds[base + 16 * l: base + 16 * l + 16] = chunk
+                    self.lds[base + 16 * l: base + 16 * l + 16] = self.mem.read(int(addrs[l]), 16)
         self._issue(w, "vm", complete)
 
     def i_global_load_lds_dwordx4(self, w, i):
