@@ -1215,7 +1215,7 @@ static int g_attn_variant = LL_ATTN_VARIANT_DEFAULT;   // 0: simple kernel, 1: s
 static int g_attn_pp_min_keys = 16 * KT;   // key ranges at least this long run the ping-pong loop (cross-attention's 512 keys: one-barrier loop)
 void ll_set_attn_pp_min_internal(int v) { g_attn_pp_min_keys = v; }
 static int g_attn_xcd = 1;
-static int g_attn_asm = 0;        // tuning key attn_asm: 1 / 2 = long contiguous key ranges run flash_attn_asm_kernel (attention_asm.hip: 4 waves x 64
+static int g_attn_asm = 1;        // tuning key attn_asm (DEFAULT 1; 0 = flash_attn_pipe_kernel<8, 1>): 1 / 2 = long contiguous key ranges run flash_attn_asm_kernel (attention_asm.hip: 4 waves x 64
                                   // rows, one wave per SIMD, generated hand-scheduled body; 1: buffer_load..lds staging, 2: global_load_lds staging)
 void ll_set_attn_asm_internal(int v) { g_attn_asm = v; }
 int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk,

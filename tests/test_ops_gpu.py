@@ -263,12 +263,14 @@ def test_flash_attn_mfma16_variant(ops, B, Lq, H, Sk, seg):
     k = hn("ak", (B, Sk, H, 128))
     v = hn("av", (B, Sk, H, 128), 0.7)
     exact = R.attention_exact(q, k[:, seg[0]:seg[1]], v[:, seg[0]:seg[1]])
-    base = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
     try:
+        _set_tuning("attn_asm", 0)
+        base = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
         _set_tuning("attn_mfma16", 1)
         got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
     finally:
         _set_tuning("attn_mfma16", 0)
+        _set_tuning("attn_asm", 1)
     err, berr = (got.double() - exact).abs().max().item(), (base.double() - exact).abs().max().item()
     assert err < 1.2e-2 and rel_l2(got, exact) < 6e-3, (err, berr, rel_l2(got, exact))
     assert (got.float() - base.float()).abs().max().item() < 8e-3
@@ -284,10 +286,12 @@ def test_flash_attn_mfma16_variant_rescale(ops):
     k[0, 1000, 0] = (q[0, 37, 0].float() * 3).to(bf)     # a query of the second 16-row block, mid-range
     exact = R.attention_exact(q, k, v)
     try:
+        _set_tuning("attn_asm", 0)
         _set_tuning("attn_mfma16", 1)
         got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [(0, Sk)]).cpu().double()
     finally:
         _set_tuning("attn_mfma16", 0)
+        _set_tuning("attn_asm", 1)
     assert (got - exact).abs().max().item() < 2e-2
 
 
@@ -306,12 +310,13 @@ def test_flash_attn_asm_kernel(ops, form, B, Lq, H, Sk, seg):
     k = hn("ak", (B, Sk, H, 128))
     v = hn("av", (B, Sk, H, 128), 0.7)
     exact = R.attention_exact(q, k[:, seg[0]:seg[1]], v[:, seg[0]:seg[1]])
-    base = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
     try:
+        _set_tuning("attn_asm", 0)
+        base = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
         _set_tuning("attn_asm", form)
         got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [seg]).cpu()
     finally:
-        _set_tuning("attn_asm", 0)
+        _set_tuning("attn_asm", 1)
     assert torch.isfinite(got.float()).all()
     err, berr = (got.double() - exact).abs().max().item(), (base.double() - exact).abs().max().item()
     assert err < 1.2e-2 and rel_l2(got, exact) < 6e-3, (err, berr, rel_l2(got, exact))
@@ -331,7 +336,7 @@ def test_flash_attn_asm_kernel_rescale(ops, form):
         _set_tuning("attn_asm", form)
         got = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), [(0, Sk)]).cpu().double()
     finally:
-        _set_tuning("attn_asm", 0)
+        _set_tuning("attn_asm", 1)
     assert (got - exact).abs().max().item() < 2e-2
 
 

@@ -47,25 +47,27 @@ def test_flash_attn_production_grids(Lq):
     import ctypes as C
     buf = C.create_string_buffer(256)
     _lib.check(_lib.load().ll_flash_attn_plan(Lq, H, 1, Lk, 0, 1, 1, buf, 256), "plan")
-    assert b"flash_attn_pipe_kernel<8, 1>" in buf.value, buf.value     # the shipped launch: one workgroup per (head, q-tile) pair
+    assert b"flash_attn_asm_kernel" in buf.value, buf.value     # the shipped launch: one 4-wave workgroup per (head, q-tile) pair
     try:
         _tuning("attn_xcd", 1)
-        got = ops.flash_attn(q, k, v, [(0, Lk)])                    # shipped: 228 / 888 workgroups, XCD-aware placement
+        got = ops.flash_attn(q, k, v, [(0, Lk)])                    # shipped: flash_attn_asm_kernel, 228 / 888 workgroups, XCD-aware placement
         _tuning("attn_xcd", 0)
         got0 = ops.flash_attn(q, k, v, [(0, Lk)])
+        _tuning("attn_xcd", 1)
+        _tuning("attn_asm", 2)                 # the same kernel with global_load_lds staging
+        asm_g = ops.flash_attn(q, k, v, [(0, Lk)])
+        _tuning("attn_asm", 0)                 # round 1-2's kernel: 8 waves x 32 rows, ping-pong wave groups
+        pipe = ops.flash_attn(q, k, v, [(0, Lk)])
+        _tuning("attn_xcd", 0)
+        pipe0 = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_sk_wgs", 0)              # opt-in stream-K form: 256 workgroups x equal key-tile runs + merge
         sk0 = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_xcd", 1)
         sk = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_sk_wgs", -1)
-        _tuning("attn_mfma16", 1)              # opt-in: the same ping-pong loop on v_mfma_f32_16x16x32_bf16
+        _tuning("attn_mfma16", 1)              # opt-in: the ping-pong loop on v_mfma_f32_16x16x32_bf16
         m16 = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_mfma16", 0)
-        asm = {}
-        for form in (1, 2):                    # opt-in: the generated one-wave-per-SIMD kernel, both staging forms
-            _tuning("attn_asm", form)
-            asm[form] = ops.flash_attn(q, k, v, [(0, Lk)])
-        _tuning("attn_asm", 0)
         _tuning("attn_variant", 0)             # plain kernel: grid (q-tile, head, batch), no remap, no pipelining
         plain = ops.flash_attn(q, k, v, [(0, Lk)])
     finally:
@@ -73,15 +75,15 @@ def test_flash_attn_production_grids(Lq):
         _tuning("attn_variant", 2)
         _tuning("attn_sk_wgs", -1)
         _tuning("attn_mfma16", 0)
-        _tuning("attn_asm", 0)
-    assert torch.equal(got, got0) and torch.equal(sk, sk0), "XCD-aware workgroup placement must not change a single bit"
+        _tuning("attn_asm", 1)
+    assert torch.equal(got, got0) and torch.equal(sk, sk0) and torch.equal(pipe, pipe0), "XCD-aware workgroup placement must not change a single bit"
+    assert torch.equal(got, asm_g), "the two staging forms of the generated kernel stage the same bytes"
     # every element: a wrong (head, q-tile) mapping or a dropped key tile is an O(1) error, far above two kernels' rounding
     d = (got.float() - plain.float()).abs()
     assert d.max().item() < 8e-3, d.max().item()
+    assert torch.equal(pipe, plain), "the ping-pong kernel and the plain one round identically"
     assert (sk.float() - plain.float()).abs().max().item() < 8e-3
     assert (m16.float() - plain.float()).abs().max().item() < 8e-3
-    for form in (1, 2):
-        assert (asm[form].float() - plain.float()).abs().max().item() < 8e-3, form
     # sampled rows, exact: two rows of every (head, 256-row q-tile) workgroup, in different waves / lane halves; plus the
     # first and last rows
     nqt = (Lq + 255) // 256

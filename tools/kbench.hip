@@ -324,6 +324,19 @@ int main(int argc, char** argv) {
    bench_gemm_i8("ffn2", 4680, 1536, 8960, iters);
    bench_gemm_i8("edge", 300, 136, 256, 2);
   }
+  if (!strcmp(what, "attnx")) {      // kbench attnx <iters> [rounds]: steady-state self-attention, shipped kernel vs the attn_asm forms, interleaved
+    const int rounds = argc > 3 ? atoi(argv[3]) : 3;
+    for (int r = 0; r < rounds; ++r)
+      for (int form = 0; form <= 2; ++form) {
+        LL(ll_set_tuning("attn_asm", form));
+        bench_attn(form == 0 ? "self/pipe" : form == 1 ? "self/asm-b" : "self/asm-g", 4680, 12, 18720, 18720, iters);
+      }
+    LL(ll_set_tuning("attn_asm", 1));
+    bench_attn("recache/asm-b", 18720, 12, 18720, 18720, iters > 5 ? 5 : iters);
+    LL(ll_set_tuning("attn_asm", 0));
+    bench_attn("recache/pipe", 18720, 12, 18720, 18720, iters > 5 ? 5 : iters);
+    return 0;
+  }
   if (all || !strcmp(what, "attn")) {
    for (int variant = 0; variant <= 2; ++variant) {
     LL(ll_set_tuning("attn_variant", variant));
