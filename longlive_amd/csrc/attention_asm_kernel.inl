@@ -2,7 +2,11 @@
 __global__ __launch_bounds__(256, 1) void LL_ASM_NAME(const bf16* __restrict__ Q, const bf16* __restrict__ Kc,
                                                                 const bf16* __restrict__ Vc, bf16* __restrict__ O, int Lq,
                                                                 int ldq, int ldo, int ldk, long long k_batch_stride, int kstart,
-                                                                int nkeys, float c, int nqt, int xcd_placement) {
+                                                                int nkeys, float c, int nqt, int xcd_placement
+#ifdef LL_ASM_DIAG
+                                                                , unsigned long long* dbg
+#endif
+) {
   // XCD-aware placement as flash_attn_pipe_kernel: workgroup ids that share an XCD (id % 8) take a contiguous head-major range
   const int b = blockIdx.z;
   int nwg_ = gridDim.x, bid_ = blockIdx.x;
@@ -36,7 +40,10 @@ __global__ __launch_bounds__(256, 1) void LL_ASM_NAME(const bf16* __restrict__ Q
       :
       : "{s[8:9]}"(qb), "{s[10:11]}"(ob), "{s[12:13]}"(kb), "{s[14:15]}"(vb), "{s16}"(ldq_b), "{s17}"(ldo_b), "{s18}"(ldk_b),
         "{s19}"(rows), "{s20}"(unt), "{s21}"(lastv), "{s22}"(c), "{s23}"(nrec), "{v0}"(tid)
-      : "memory", "v255", "a255", "s63", "vcc");
+#ifdef LL_ASM_DIAG
+        , "{s[56:57]}"(dbg), "{s58}"(lid_ + gridDim.x * b)
+#endif
+      : "memory", "v255", "a255", "s79", "vcc");
   __builtin_unreachable();
 }
 

@@ -50,6 +50,10 @@ DMA = "buffer"                               # "buffer": buffer_load ... lds thr
                                              # "global": global_load_lds with a scalar tile base that stops at the last tile and row
                                              #           offsets that switch to clamped rows for the ragged last tile (no descriptor)
 PFX = "LL"                                   # label prefix (one per kernel in the translation unit)
+DIAG = False                                 # diagnostic build only (tools/attn_asm_diag.hip): s_memtime stamps around the phases of every
+                                             # tile, summed per wave and stored to a debug buffer (s[56:57] + 32 * (4 * s58 + wave)); never in the library
+S_DBG, S_WG = 56, 58
+S_TS, S_ACC = 60, 64                         # last stamp s[60:61]; sums s[64:65] A, s[66:67] B, s[68:69] wait+barrier, s[70:71] whole loop
 
 A_O, A_Q, A_K = 0, 128, 192
 V_S, V_NM, V_VF = 0, 128, 160
@@ -308,9 +312,9 @@ def ret_dispatch(g: Gen, ret_labels):
 
 
 # ---- the kernel -------------------------------------------------------------------------------------------------------
-def generate(dma: str = "buffer", prefix: str = "LL") -> str:
-    global DMA, PFX
-    DMA, PFX = dma, prefix
+def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str:
+    global DMA, PFX, DIAG
+    DMA, PFX, DIAG = dma, prefix, diag
     g = Gen()
     I = g.I
     # ================= setup =================
@@ -455,6 +459,11 @@ def generate(dma: str = "buffer", prefix: str = "LL") -> str:
     I("s_waitcnt lgkmcnt(0)")
     I("s_barrier")                                    # (2) K(0) has been read by every wave: its slot may be refilled
     I(f"s_mov_b32 {sreg(S_I)}, 1")
+    if DIAG:
+        for k in range(8):
+            I(f"s_mov_b32 {sreg(S_ACC + k)}, 0")
+        stamp(g)
+        I(f"s_mov_b64 s[72:73], {sreg(S_TS, 2)}")
     # ================= main loop, unrolled by 4 (ring slots and score-buffer parity are static per copy) =================
     g.L("LL_LOOP")
     for u in (1, 2, 3, 0):
@@ -488,6 +497,21 @@ def generate(dma: str = "buffer", prefix: str = "LL") -> str:
     g.L("LL_EPILOGUE")
     I("s_nop 15")
     I("s_nop 15")
+    if DIAG:
+        stamp(g)
+        I(f"s_sub_u32 {sreg(S_ACC + 6)}, {sreg(S_TS)}, s72")
+        I(f"s_subb_u32 {sreg(S_ACC + 7)}, {sreg(S_TS + 1)}, s73")
+        I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_WG)}, 2")
+        I(f"s_add_u32 {sreg(S_T0)}, {sreg(S_T0)}, {sreg(S_WAVE)}")
+        I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_T0)}, 5")
+        I(f"v_mov_b32 {vreg(V_T)}, {sreg(S_T0)}")
+        for k in range(8):
+            I(f"v_mov_b32 {vreg(V_T + 2 + k)}, {sreg(S_ACC + k)}")
+        I(f"v_cmp_eq_u32_e64 {sreg(S_M0, 2)}, {vreg(V_LANE)}, 0")
+        I(f"s_mov_b64 exec, {sreg(S_M0, 2)}")
+        I(f"global_store_dwordx4 {vreg(V_T)}, {vreg(V_T + 2, 4)}, {sreg(S_DBG, 2)}")
+        I(f"global_store_dwordx4 {vreg(V_T)}, {vreg(V_T + 6, 4)}, {sreg(S_DBG, 2)} offset:16")
+        I("s_mov_b64 exec, -1")
     gen_epilogue(g)
     I("s_waitcnt vmcnt(0)")
     I("s_endpgm")
@@ -521,6 +545,20 @@ def mask_rets(x):
     return [f"LL_MASK_RET_{u}" for u in ((0, 2) if x == 0 else (1, 3))]
 
 
+def stamp(g: Gen, acc=None):
+    """diagnostic: s[62:63] = now; if acc: acc += now - last; last = now"""
+    if not DIAG:
+        return
+    g.I("s_memtime s[62:63]")
+    g.I("s_waitcnt lgkmcnt(0)")
+    if acc is not None:
+        g.I(f"s_sub_u32 {sreg(S_T2)}, s62, {sreg(S_TS)}")
+        g.I(f"s_subb_u32 {sreg(S_T3)}, s63, {sreg(S_TS + 1)}")
+        g.I(f"s_add_u32 {sreg(acc)}, {sreg(acc)}, {sreg(S_T2)}")
+        g.I(f"s_addc_u32 {sreg(acc + 1)}, {sreg(acc + 1)}, {sreg(S_T3)}")
+    g.I(f"s_mov_b64 {sreg(S_TS, 2)}, s[62:63]")
+
+
 def gen_tile(g: Gen, u: int):
     """tile i with i % 4 == u (i >= 1): phases A_i and B_i, the barrier, the rare branches"""
     I = g.I
@@ -531,6 +569,7 @@ def gen_tile(g: Gen, u: int):
         for k, op in enumerate(v_frag_reads(n, u - 1)):
             fillers.append((22 + 2 * n + 0.9 + 0.05 * k, op))
     g.phase(qk_mfmas(x), fillers)
+    stamp(g, S_ACC)
     # ragged last tile: mask S(i) before its row max is taken
     I(f"s_add_u32 {sreg(S_T0)}, {sreg(S_I)}, 1")
     I(f"s_cmp_lg_u32 {sreg(S_T0)}, {sreg(S_NT)}")
@@ -556,8 +595,10 @@ def gen_tile(g: Gen, u: int):
     I(f"s_mov_b32 {sreg(S_RET)}, {rescale_rets(x).index(f'LL_RESC_RET_{u}')}")
     I(f"s_branch LL_RESCALE_{x}")
     g.L(f"LL_RESC_RET_{u}")
+    stamp(g, S_ACC + 2)
     I("s_waitcnt vmcnt(8)")                           # everything but this tile's 8 pieces has landed: K(i+2), V(i) are in LDS
     I("s_barrier")
+    stamp(g, S_ACC + 4)
 
 
 def gen_epilogue(g: Gen):
@@ -745,11 +786,14 @@ def to_inc(text):
 
 if __name__ == "__main__":
     mode = "buffer"
+    diag = "--diag" in sys.argv
+    if diag:
+        sys.argv.remove("--diag")
     if "--dma" in sys.argv:
         k = sys.argv.index("--dma")
         mode = sys.argv[k + 1]
         del sys.argv[k:k + 2]
-    txt = generate(mode, "LL" + mode[0].upper())
+    txt = generate(mode, "LL" + mode[0].upper() + ("D" if diag else ""), diag)
     probs = lint(txt)
     for p in probs[:40]:
         print("LINT:", p, file=sys.stderr)

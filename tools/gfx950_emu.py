@@ -352,6 +352,14 @@ class Machine:
         if "lgkmcnt" in i.mods:
             self._retire(w, "lgkm", i.mods["lgkmcnt"])
 
+    def i_s_memtime(self, w, i):
+        self.ws(w, i.ops[0], w.n_exec * 4, 2)
+
+    def i_s_subb_u32(self, w, i):
+        c = w.scc
+        a, b, r = self._sarith(w, i, lambda a, b: a - b - c)
+        w.scc = 1 if b + c > a else 0
+
     def i_s_mov_b32(self, w, i): self.ws(w, i.ops[0], self.rs(w, i.ops[1]))
     def i_s_mov_b64(self, w, i): self.ws(w, i.ops[0], self.rs(w, i.ops[1], 2), 2)
 
