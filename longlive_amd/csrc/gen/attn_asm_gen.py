@@ -53,16 +53,18 @@ PFX = "LL"                                   # label prefix (one per kernel in t
 DIAG = False                                 # diagnostic build only (tools/attn_asm_diag.hip): s_memtime stamps around the phases of every
                                              # tile, summed per wave and stored to a debug buffer (s[56:57] + 32 * (4 * s58 + wave)); never in the library
 S_DBG, S_WG = 56, 58
+import os as _os
+KNOB = lambda name, default: type(default)(_os.environ.get("ASM_" + name, default))    # schedule experiments (tools/attn_asm_diag)
 S_TS, S_ACC = 60, 64                         # last stamp s[60:61]; sums s[64:65] A, s[66:67] B, s[68:69] wait+barrier, s[70:71] whole loop
 
 A_O, A_Q, A_K = 0, 128, 192
 V_S, V_NM, V_VF = 0, 128, 160
 V_KOFF, V_VOFF, V_DK, V_DV = 192, 200, 204, 208      # 8 K-read offsets, 4 V-read offsets, 4 + 4 DMA source offsets
-V_L = 212                                     # l[qb][2] partial row sums -> 212..215
-V_MX = 216                                    # mx[qb] tile max (cross-half) -> 216, 217
-V_T = 218                                     # temporaries 218..231
-V_LANE, V_R, V_H = 232, 233, 234
-V_ROW = 236                                   # per-qb row index within the workgroup -> 236, 237
+V_L = 212                                     # l[qb][4] partial row sums -> 212..219 (an element in VGPR bank b adds into the partial of bank b + 1)
+V_MX = 220                                    # mx[qb] tile max (cross-half) -> 220, 221
+V_T = 222                                     # temporaries 222..235
+V_LANE, V_R, V_H = 236, 237, 238
+V_ROW = 248                                   # per-qb row index within the workgroup -> 236, 237
 V_TID = 0                                     # input: workitem id
 
 KSLOT = lambda s: 16384 * (s & 3)             # LDS: K ring at 0, V ring at 64 KiB
@@ -162,10 +164,11 @@ def k_frag_reads(kslot):
     return out
 
 
-def finish_ops(y):
+def finish_ops(y, with_pos=False):
     """exp2, row-sum and pack of S(y) -> P in place.  Order = the order PV consumes the fragments: k-step, then qb.  Emitted as a
-    software pipeline (exp of element n, add of element n-2, pack of a pair two further back) so that no instruction depends on
-    its predecessor."""
+    software pipeline (exp of element n, add of element n - DA, pack of a pair DC back) so that no instruction depends on its
+    near predecessors.  with_pos: (element index the op belongs to, text) so that the caller can place ops by deadline."""
+    DA, DC = KNOB("FIN_DA", 2), KNOB("FIN_DC", 5)
     elems = []
     for kstep in range(4):
         for qb in range(2):
@@ -174,37 +177,48 @@ def finish_ops(y):
                 elems.append((qb, base + j, P_f(y, qb, kstep) + (j >> 1), j))
     ops = []
     n = len(elems)
-    for t in range(n + 5):
+    noexp = KNOB("NO_EXP", 0)
+    for t in range(n + DC + 1):
         if t < n:
-            ops.append(f"v_exp_f32 {vreg(elems[t][1])}, {vreg(elems[t][1])}")
-        if 2 <= t < n + 2:
-            qb, r, _, j = elems[t - 2]
-            l = V_L + 2 * qb + (j & 1)
-            ops.append(f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(r)}")
-        if t >= 5 and (t - 5) % 2 == 0 and t - 5 < n:
-            qb, r0, dst, j = elems[t - 5]
-            ops.append(f"v_cvt_pk_bf16_f32 {vreg(dst)}, {vreg(r0)}, {vreg(r0 + 1)}")
-    return ops
+            ops.append((t, (f"v_mov_b32 {vreg(elems[t][1])}, {vreg(elems[t][1])}" if noexp else f"v_exp_f32 {vreg(elems[t][1])}, {vreg(elems[t][1])}")))
+        if DA <= t < n + DA:
+            qb, r, _, j = elems[t - DA]
+            l = V_L + 4 * qb + (((r & 3) + 1) & 3 if KNOB("BANKS", 1) else (j & 1))
+            ops.append((t, f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(r)}"))
+        if t >= DC and (t - DC) % 2 == 0 and t - DC < n:
+            qb, r0, dst, j = elems[t - DC]
+            ops.append((t, f"v_cvt_pk_bf16_f32 {vreg(dst)}, {vreg(r0)}, {vreg(r0 + 1)}"))
+    if KNOB("NO_FIN", 0):
+        ops = []
+    return ops if with_pos else [o for _, o in ops]
 
 
 def start_ops(x):
     """row max of S(x) per q-block (two chains per q-block, merged), cross-half exchange, rescale decision masks in S_M0 / S_M1"""
     ops = []
     chains = []
+    finals = []
     for qb in range(2):
         for kb in range(2):
-            b = S_t(x, qb, kb)
-            t = V_T + 2 * qb + kb
-            c = [f"v_max3_f32 {vreg(t)}, {vreg(b)}, {vreg(b + 1)}, {vreg(b + 2)}"]
+            b = S_t(x, qb, kb)                        # 16-aligned: register b + j sits in VGPR bank j & 3
+            ci = 2 * qb + kb
+            ta, tb = (253, 250, 254, V_T + 11)[ci], (252, 251, 255, V_T + 10)[ci]
+            # (ta in VGPR bank 1 or 2, read next to operands in banks 3, 0; tb in bank 0 or 3, next to banks 1, 2 -- measured: no effect)
+            cur = ta
+            c = [f"v_max3_f32 {vreg(cur)}, {vreg(b)}, {vreg(b + 1)}, {vreg(b + 2)}"]
             for j in range(3, 15, 2):
-                c.append(f"v_max3_f32 {vreg(t)}, {vreg(t)}, {vreg(b + j)}, {vreg(b + j + 1)}")
-            c.append(f"v_max_f32 {vreg(t)}, {vreg(t)}, {vreg(b + 15)}")
+                nxt = tb if cur == ta else ta
+                c.append(f"v_max3_f32 {vreg(nxt)}, {vreg(cur)}, {vreg(b + j)}, {vreg(b + j + 1)}")
+                cur = nxt
+            nxt = tb if cur == ta else ta
+            c.append(f"v_max_f32 {vreg(nxt)}, {vreg(cur)}, {vreg(b + 15)}")
+            finals.append(nxt)
             chains.append(c)
     for step in range(len(chains[0])):               # round-robin over the four chains: 3 independent ops between dependents
         for c in chains:
             ops.append(c[step])
     for qb in range(2):
-        ops.append(f"v_max_f32 {vreg(V_MX + qb)}, {vreg(V_T + 2 * qb)}, {vreg(V_T + 2 * qb + 1)}")
+        ops.append(f"v_max_f32 {vreg(V_MX + qb)}, {vreg(finals[2 * qb])}, {vreg(finals[2 * qb + 1])}")
     for qb in range(2):
         ops.append(f"v_mov_b32 {vreg(V_T + 4 + qb)}, {vreg(V_MX + qb)}")
     ops.append("s_nop 0")
@@ -269,8 +283,8 @@ def gen_rescale(g: Gen, x: int, ret_labels):
         g.I(f"v_exp_f32_e64 {vreg(f)}, -{vreg(d)}")
     for qb in range(2):
         d, f = V_T + 6 + qb, V_T + 8 + qb
-        for k in range(2):
-            g.I(f"v_mul_f32 {vreg(V_L + 2 * qb + k)}, {vreg(V_L + 2 * qb + k)}, {vreg(f)}")
+        for k in range(4):
+            g.I(f"v_mul_f32 {vreg(V_L + 4 * qb + k)}, {vreg(V_L + 4 * qb + k)}, {vreg(f)}")
         for r in range(16):
             g.I(f"v_sub_f32 {vreg(V_NM + 16 * qb + r)}, {vreg(V_NM + 16 * qb + r)}, {vreg(d)}")
         for kb in range(2):
@@ -422,7 +436,7 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     # O = 0, l = 0 while the loads fly
     for r in range(128):
         I(f"v_accvgpr_write_b32 {areg(A_O + r)}, 0")
-    for k in range(4):
+    for k in range(8):
         I(f"v_mov_b32 {vreg(V_L + k)}, 0")
     I("s_waitcnt vmcnt(0)")                           # Q, and every staged tile of the prologue
     for qb in range(2):
@@ -564,10 +578,18 @@ def gen_tile(g: Gen, u: int):
     I = g.I
     x, y = u & 1, (u & 1) ^ 1
     # ---- A_i: S(i) = K(i) Q^T  ||  finish(i-1)  ||  first V(i-1) fragments
-    fillers = spread(finish_ops(y), 0.3, 31.0)
+    fin = finish_ops(y, with_pos=True)
+    span = KNOB("FIN_SPAN", 31.0)                    # finish(i-1) is spread over this many MFMA gaps from the start of A_i; beyond 32 it
+    tmax = max([t for t, _ in fin] + [0])            # runs on into B_i, ahead of the P.V k-steps that consume it (k-step k starts at B gap 8 k)
+    placed = [(0.3 + span * t / (tmax + 1) + 0.001 * k, op) for k, (t, op) in enumerate(fin)]
+    fillers = [(p_, op) for p_, op in placed if p_ < 32]
+    fin_b = [(p_ - 32, op) for p_, op in placed if p_ >= 32]
     for n in range(5):                                # fragments 0..4 of V(i-1): ten gaps ahead of their first use
         for k, op in enumerate(v_frag_reads(n, u - 1)):
             fillers.append((22 + 2 * n + 0.9 + 0.05 * k, op))
+    dma_a = KNOB("DMA_IN_A", 0)
+    if dma_a and not KNOB("NO_DMA", 0):
+        fillers += spread(dma_ops(u + 3, u + 2), 1.4, 30.5)
     g.phase(qk_mfmas(x), fillers)
     stamp(g, S_ACC)
     # ragged last tile: mask S(i) before its row max is taken
@@ -581,13 +603,15 @@ def gen_tile(g: Gen, u: int):
     g.L(f"LL_MASK_RET_{u}")
     # ---- B_i: O^T += V(i-1)^T P(i-1)^T  ||  start(i)  ||  K(i+1) -> AGPRs, V(i-1) fragments 5..15  ||  LDS-DMA K(i+3), V(i+2)
     fillers = []
-    for k, op in enumerate(k_frag_reads(u + 1)):
-        fillers.append((0.5 + k * 0.95, op))
+    for k, op in enumerate([] if KNOB("NO_KREAD", 0) else k_frag_reads(u + 1)):
+        fillers.append((0.5 + k * KNOB("KREAD_STEP", 0.95), op))
     for n in range(5, 16):
         for k, op in enumerate(v_frag_reads(n, u - 1)):
             fillers.append((2 * n - 10 + 0.9 + 0.05 * k, op))
-    fillers += spread(start_ops(x), 3.2, 22.0)
-    fillers += spread(dma_ops(u + 3, u + 2), 16.4, 31.5)
+    fillers += spread(start_ops(x)[(-3 if KNOB("NO_START", 0) else 0):], 3.2, KNOB("START_END", 22.0))
+    if not dma_a and not KNOB("NO_DMA", 0):
+        fillers += spread(dma_ops(u + 3, u + 2), 16.4, 31.5)
+    fillers += fin_b
     g.phase(pv_mfmas(y), fillers)
     # rescale decision (after every P.V of tile i-1 has issued), then the tile barrier
     I(f"s_or_b64 {sreg(S_M0, 2)}, {sreg(S_M0, 2)}, {sreg(S_M1, 2)}")
@@ -607,18 +631,22 @@ def gen_epilogue(g: Gen):
     (d = 32 db + 8 (k + h) .. +7): 8 x 16-byte stores per q-block (T21)."""
     I = g.I
     for qb in range(2):
-        l, t = V_L + 2 * qb, V_T + qb
+        l = V_L + 4 * qb
         I(f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(l + 1)}")
+        I(f"v_add_f32 {vreg(l + 2)}, {vreg(l + 2)}, {vreg(l + 3)}")
     for qb in range(2):
-        I(f"v_mov_b32 {vreg(V_T + qb)}, {vreg(V_L + 2 * qb)}")
+        l = V_L + 4 * qb
+        I(f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(l + 2)}")
+    for qb in range(2):
+        I(f"v_mov_b32 {vreg(V_T + qb)}, {vreg(V_L + 4 * qb)}")
     I("s_nop 0")
     for qb in range(2):
-        I(f"v_permlane32_swap_b32 {vreg(V_L + 2 * qb)}, {vreg(V_T + qb)}")
+        I(f"v_permlane32_swap_b32 {vreg(V_L + 4 * qb)}, {vreg(V_T + qb)}")
     for qb in range(2):
-        I(f"v_add_f32 {vreg(V_L + 2 * qb)}, {vreg(V_L + 2 * qb)}, {vreg(V_T + qb)}")
-        I(f"v_rcp_f32 {vreg(V_L + 2 * qb)}, {vreg(V_L + 2 * qb)}")
+        I(f"v_add_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}, {vreg(V_T + qb)}")
+        I(f"v_rcp_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}")
     for qb in range(2):
-        inv = V_L + 2 * qb
+        inv = V_L + 4 * qb
         # output row address: O base + row * ldo + (4 h elements -> the swap moves it to 8 (k + h)) ; 64-bit
         I(f"v_mul_lo_u32 {vreg(V_T + 2)}, {vreg(V_ROW + qb)}, {sreg(S_LDO)}")
         I(f"v_lshl_add_u32 {vreg(V_T + 2)}, {vreg(V_H)}, 4, {vreg(V_T + 2)}")            # + 16 h bytes
