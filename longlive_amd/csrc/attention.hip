@@ -1215,8 +1215,8 @@ static int g_attn_variant = LL_ATTN_VARIANT_DEFAULT;   // 0: simple kernel, 1: s
 static int g_attn_pp_min_keys = 16 * KT;   // key ranges at least this long run the ping-pong loop (cross-attention's 512 keys: one-barrier loop)
 void ll_set_attn_pp_min_internal(int v) { g_attn_pp_min_keys = v; }
 static int g_attn_xcd = 1;
-static int g_attn_asm = 1;        // tuning key attn_asm (DEFAULT 1; 0 = flash_attn_pipe_kernel<8, 1>): 1 / 2 = long contiguous key ranges run flash_attn_asm_kernel (attention_asm.hip: 4 waves x 64
-                                  // rows, one wave per SIMD, generated hand-scheduled body; 1: buffer_load..lds staging, 2: global_load_lds staging)
+static int g_attn_asm = 1;        // tuning key attn_asm (DEFAULT 1; 0 = flash_attn_pipe_kernel<8, 1>): long contiguous key ranges run flash_attn_asm_kernel
+                                  // (attention_asm.hip: 4 waves x 64 rows, one wave per SIMD, generated hand-scheduled body)
 void ll_set_attn_asm_internal(int v) { g_attn_asm = v; }
 int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk,
                           long long k_batch_stride, int kstart, int nkeys, float c, int xcd, int form, hipStream_t stream);
@@ -1316,7 +1316,7 @@ extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_l
                "flash_attn_sk_combine_kernel<8>", W, ((long long)nqt * H * B * ((n0 + KT - 1) / KT) + W - 1) / W);
     else if (attn_asm_eligible(n0, H * 128))
       snprintf(out, (size_t)cap, "%s (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups of 256 query rows%s",
-               g_attn_asm == 2 ? "flash_attn_asm_g_kernel" : "flash_attn_asm_kernel", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
+               "flash_attn_asm_kernel", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
     else if (pp && g_attn_mfma16)
       snprintf(out, (size_t)cap, "flash_attn_pipe16_kernel<8> (ping-pong wave groups, MFMA 16x16x32), %d workgroups of 256 query rows%s",
                nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");

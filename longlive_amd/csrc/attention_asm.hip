@@ -12,27 +12,16 @@
 #include "attention_asm_kernel.inl"
 #undef LL_ASM_NAME
 #undef LL_ASM_INC
-// same kernel with global_load_lds staging (scalar tile base, clamped rows) instead of buffer_load ... lds through a descriptor
-#define LL_ASM_NAME flash_attn_asm_g_kernel
-#define LL_ASM_INC "build/attn_asm_body_g.inc"
-#include "attention_asm_kernel.inl"
-#undef LL_ASM_NAME
-#undef LL_ASM_INC
-
 int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk,
                           long long k_batch_stride, int kstart, int nkeys, float c, int xcd, int form, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)flash_attn_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void*)flash_attn_asm_g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
   const int nqt = (Lq + 255) / 256;
-  if (form == 2)
-    hipLaunchKernelGGL(flash_attn_asm_g_kernel, dim3(nqt * H, 1, B), dim3(256), 128 * 1024, stream, q, k, v, out, Lq, ldq, ldo, ldk,
-                       k_batch_stride, kstart, nkeys, c, nqt, xcd);
-  else
-    hipLaunchKernelGGL(flash_attn_asm_kernel, dim3(nqt * H, 1, B), dim3(256), 128 * 1024, stream, q, k, v, out, Lq, ldq, ldo, ldk,
+  (void)form;
+  hipLaunchKernelGGL(flash_attn_asm_kernel, dim3(nqt * H, 1, B), dim3(256), 128 * 1024, stream, q, k, v, out, Lq, ldq, ldo, ldk,
                        k_batch_stride, kstart, nkeys, c, nqt, xcd);
   return ll_check_launch("ll_flash_attn(asm)");
 }

@@ -43,12 +43,9 @@ S_WAVE, S_I, S_STEP, S_T0, S_T1, S_T2, S_T3 = 32, 33, 34, 36, 37, 38, 39
 S_M0, S_M1 = 40, 42                          # 64-bit lane masks
 S_THR, S_NINF, S_RET, S_KM0, S_VM0 = 48, 49, 50, 52, 53
 THR = 8.0                                    # lazy-max threshold in log2 units (P <= 2^8 between rescales)
-S_NTM1, S_C0, S_C1 = 54, 44, 46              # global-DMA mode: nt - 1, two 64-bit select masks
-V_DKL, V_DVL = 240, 244                      # global-DMA mode: DMA source offsets with rows clamped to the ragged last tile
-DMA = "buffer"                               # "buffer": buffer_load ... lds through a descriptor whose num_records shrinks tile by tile
-                                             #           (rows past the key range read as zeros, tiles past the end are all zeros)
-                                             # "global": global_load_lds with a scalar tile base that stops at the last tile and row
-                                             #           offsets that switch to clamped rows for the ragged last tile (no descriptor)
+DMA = "buffer"                               # buffer_load ... lds through a descriptor whose num_records shrinks tile by tile: rows past the key
+                                             # range read as zeros, tiles past the end are all zeros (a global_load_lds form with clamped tiles /
+                                             # rows existed and staged identical bytes 1.5 % slower: round-3 notes in DESIGN.md)
 PFX = "LL"                                   # label prefix (one per kernel in the translation unit)
 DIAG = False                                 # diagnostic build only (tools/attn_asm_diag.hip): s_memtime stamps around the phases of every
                                              # tile, summed per wave and stored to a debug buffer (s[56:57] + 32 * (4 * s58 + wave)); never in the library
@@ -58,13 +55,15 @@ KNOB = lambda name, default: type(default)(_os.environ.get("ASM_" + name, defaul
 S_TS, S_ACC = 60, 64                         # last stamp s[60:61]; sums s[64:65] A, s[66:67] B, s[68:69] wait+barrier, s[70:71] whole loop
 
 A_O, A_Q, A_K = 0, 128, 192
-V_S, V_NM, V_VF = 0, 128, 160
-V_KOFF, V_VOFF, V_DK, V_DV = 192, 200, 204, 208      # 8 K-read offsets, 4 V-read offsets, 4 + 4 DMA source offsets
-V_L = 212                                     # l[qb][4] partial row sums -> 212..219 (an element in VGPR bank b adds into the partial of bank b + 1)
-V_MX = 220                                    # mx[qb] tile max (cross-half) -> 220, 221
-V_T = 222                                     # temporaries 222..235
+V_S, V_NM, V_VF = 0, 128, 160                # S buffers 0..127, -m tiles 128..159, ring of 4 V^T fragments 160..175
+NVF = 4
+V_LACC = 176                                  # row-sum accumulators LACC[qb][0:15] 176..207: D of the ones-MFMA (every register of a lane = its query's sum)
+V_KOFF, V_VOFF, V_DK, V_DV = 208, 216, 220, 224      # 8 K-read offsets, 4 V-read offsets, 4 + 4 DMA source offsets
+V_ONES = 228                                  # 228..231: bf16 1.0 in every element (A operand of the row-sum MFMA)
+V_MX = 232                                    # mx[qb] tile max (cross-half) -> 232, 233
+V_ROW = 234                                   # per-qb row index within the workgroup -> 234, 235
 V_LANE, V_R, V_H = 236, 237, 238
-V_ROW = 248                                   # per-qb row index within the workgroup -> 236, 237
+V_T = 240                                     # temporaries 240..253
 V_TID = 0                                     # input: workitem id
 
 KSLOT = lambda s: 16384 * (s & 3)             # LDS: K ring at 0, V ring at 64 KiB
@@ -136,22 +135,33 @@ def qk_mfmas(x):
 
 
 def pv_mfmas(y):
-    """O^T += V^T P^T with P of buffer y: k-step outer, db, qb -- every V fragment (ring slot n % 8) feeds two consecutive MFMAs."""
+    """O^T += V^T P^T with P of buffer y: k-step outer, db, qb -- every V fragment (ring slot n % NVF) feeds two consecutive MFMAs.
+    After the eight MFMAs of a k-step, two more sum its P over the keys on the matrix pipe: A = all ones, so every row of the
+    32 x 32 result -- every register of a lane -- is the lane's query's sum over the 16 keys of BOTH halves (no VALU adds, no
+    cross-half exchange, and the sum is taken of the bf16 values the P.V product uses)."""
     out = []
     for kstep in range(4):
         for db in range(4):
             n = 4 * kstep + db
             for qb in range(2):
                 o = areg(A_O + 64 * qb + 16 * db, 16)
-                out.append(f"v_mfma_f32_32x32x16_bf16 {o}, {vreg(V_VF + 4 * (n % 8), 4)}, {vreg(P_f(y, qb, kstep), 4)}, {o}")
+                out.append(f"v_mfma_f32_32x32x16_bf16 {o}, {vreg(V_VF + 4 * (n % NVF), 4)}, {vreg(P_f(y, qb, kstep), 4)}, {o}")
+        for qb in range(2):
+            l = vreg(V_LACC + 16 * qb, 16)
+            out.append(f"v_mfma_f32_32x32x16_bf16 {l}, {vreg(V_ONES, 4)}, {vreg(P_f(y, qb, kstep), 4)}, {l}")
     return out
+
+
+def pv_index(n):
+    """index of the first of the two MFMAs that consume V^T fragment n"""
+    return 10 * (n >> 2) + 2 * (n & 3)
 
 
 def v_frag_reads(n, vslot):
     """the two transposed reads of V^T fragment n = (kstep, db) of the tile in ring slot vslot"""
     kstep, db = n >> 2, n & 3
     base = VSLOT(vslot) - 65536 + (32 * (kstep >> 1) + 16 * (kstep & 1)) * 256      # V_VOFF registers carry the +65536
-    d = V_VF + 4 * (n % 8)
+    d = V_VF + 4 * (n % NVF)
     return [f"ds_read_b64_tr_b16 {vreg(d, 2)}, {vreg(V_VOFF + db)} offset:{base}",
             f"ds_read_b64_tr_b16 {vreg(d + 2, 2)}, {vreg(V_VOFF + db)} offset:{base + 8 * 256}"]
 
@@ -165,10 +175,10 @@ def k_frag_reads(kslot):
 
 
 def finish_ops(y, with_pos=False):
-    """exp2, row-sum and pack of S(y) -> P in place.  Order = the order PV consumes the fragments: k-step, then qb.  Emitted as a
+    """exp2 and pack of S(y) -> P in place (the row sum is taken by the matrix pipe: pv_mfmas).  Order = the order PV consumes the fragments: k-step, then qb.  Emitted as a
     software pipeline (exp of element n, add of element n - DA, pack of a pair DC back) so that no instruction depends on its
     near predecessors.  with_pos: (element index the op belongs to, text) so that the caller can place ops by deadline."""
-    DA, DC = KNOB("FIN_DA", 2), KNOB("FIN_DC", 5)
+    DC = KNOB("FIN_DC", 3)
     elems = []
     for kstep in range(4):
         for qb in range(2):
@@ -178,13 +188,9 @@ def finish_ops(y, with_pos=False):
     ops = []
     n = len(elems)
     noexp = KNOB("NO_EXP", 0)
-    for t in range(n + DC + 1):
+    for t in range(n + DC + 2):
         if t < n:
             ops.append((t, (f"v_mov_b32 {vreg(elems[t][1])}, {vreg(elems[t][1])}" if noexp else f"v_exp_f32 {vreg(elems[t][1])}, {vreg(elems[t][1])}")))
-        if DA <= t < n + DA:
-            qb, r, _, j = elems[t - DA]
-            l = V_L + 4 * qb + (((r & 3) + 1) & 3 if KNOB("BANKS", 1) else (j & 1))
-            ops.append((t, f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(r)}"))
         if t >= DC and (t - DC) % 2 == 0 and t - DC < n:
             qb, r0, dst, j = elems[t - DC]
             ops.append((t, f"v_cvt_pk_bf16_f32 {vreg(dst)}, {vreg(r0)}, {vreg(r0 + 1)}"))
@@ -202,7 +208,7 @@ def start_ops(x):
         for kb in range(2):
             b = S_t(x, qb, kb)                        # 16-aligned: register b + j sits in VGPR bank j & 3
             ci = 2 * qb + kb
-            ta, tb = (253, 250, 254, V_T + 11)[ci], (252, 251, 255, V_T + 10)[ci]
+            ta, tb = V_T + 6 + 2 * ci, V_T + 7 + 2 * ci
             # (ta in VGPR bank 1 or 2, read next to operands in banks 3, 0; tb in bank 0 or 3, next to banks 1, 2 -- measured: no effect)
             cur = ta
             c = [f"v_max3_f32 {vreg(cur)}, {vreg(b)}, {vreg(b + 1)}, {vreg(b + 2)}"]
@@ -237,28 +243,16 @@ def dma_pieces(which, slot):
     m0b, ring, off, rs = (S_KM0, KSLOT, V_DK, S_KRS) if which == "K" else (S_VM0, VSLOT, V_DV, S_VRS)
     for i in range(4):
         ops.append(f"s_add_u32 m0, {sreg(m0b)}, {ring(slot) + 1024 * i}")
-        if DMA == "buffer":
-            ops.append(f"buffer_load_dwordx4 {vreg(off + i)}, {sreg(rs, 4)}, 0 offen lds")
-        else:
-            ops.append(f"global_load_lds_dwordx4 {vreg(off + i)}, {sreg(rs, 2)}")
+        ops.append(f"buffer_load_dwordx4 {vreg(off + i)}, {sreg(rs, 4)}, 0 offen lds")
     return ops
 
 
 def dma_step(which):
-    """advance the tile source to the next tile"""
-    rs, off, offl, cm = (S_KRS, V_DK, V_DKL, S_C0) if which == "K" else (S_VRS, V_DV, V_DVL, S_C1)
-    if DMA == "buffer":
-        return [f"s_add_u32 {sreg(rs)}, {sreg(rs)}, {sreg(S_STEP)}", f"s_addc_u32 {sreg(rs + 1)}, {sreg(rs + 1)}, 0",
-                f"s_sub_i32 {sreg(rs + 2)}, {sreg(rs + 2)}, {sreg(S_STEP)}", f"s_max_i32 {sreg(rs + 2)}, {sreg(rs + 2)}, 0"]
-    ops = [f"s_add_u32 {sreg(rs + 2)}, {sreg(rs + 2)}, 1",                 # index of the next tile to stage
-           f"s_cmp_lt_u32 {sreg(rs + 2)}, {sreg(S_NT)}",
-           f"s_cselect_b32 {sreg(S_T2)}, {sreg(S_STEP)}, 0",               # past the end: stay on the last tile
-           f"s_add_u32 {sreg(rs)}, {sreg(rs)}, {sreg(S_T2)}", f"s_addc_u32 {sreg(rs + 1)}, {sreg(rs + 1)}, 0",
-           f"s_cmp_eq_u32 {sreg(rs + 2)}, {sreg(S_NTM1)}",                 # the next one is the (ragged) last tile: clamped rows from here on
-           f"s_cselect_b64 {sreg(cm, 2)}, -1, 0"]
-    for i in range(4):
-        ops.append(f"v_cndmask_b32_e64 {vreg(off + i)}, {vreg(off + i)}, {vreg(offl + i)}, {sreg(cm, 2)}")
-    return ops
+    """advance the tile source to the next tile: base += one tile, num_records -= one tile (floored at 0: past the end every
+    lane is out of range and the hardware returns zeros)"""
+    rs = S_KRS if which == "K" else S_VRS
+    return [f"s_add_u32 {sreg(rs)}, {sreg(rs)}, {sreg(S_STEP)}", f"s_addc_u32 {sreg(rs + 1)}, {sreg(rs + 1)}, 0",
+            f"s_sub_i32 {sreg(rs + 2)}, {sreg(rs + 2)}, {sreg(S_STEP)}", f"s_max_i32 {sreg(rs + 2)}, {sreg(rs + 2)}, 0"]
 
 
 def dma_ops(kslot, vslot):
@@ -276,15 +270,14 @@ def gen_rescale(g: Gen, x: int, ret_labels):
     """Some query's tile max exceeded m_ref + THR (S_M0 | S_M1 != 0).  Runs AFTER every P.V of the pending tile has issued
     (T13's safe order).  Per lane: d = max(mx, 0); f = 2^-d; O *= f; l *= f; NM -= d (m_ref += d); S(x) -= d."""
     g.I("s_nop 15")
-    g.I("s_nop 15")                                   # the last P.V MFMAs have written their accumulators
+    g.I("s_nop 15")                                   # the last P.V / row-sum MFMAs have written their accumulators
     for qb in range(2):
-        d, f = V_T + 6 + qb, V_T + 8 + qb
+        d, f = V_T + qb, V_T + 2 + qb
         g.I(f"v_max_f32 {vreg(d)}, {vreg(V_MX + qb)}, 0")
         g.I(f"v_exp_f32_e64 {vreg(f)}, -{vreg(d)}")
     for qb in range(2):
-        d, f = V_T + 6 + qb, V_T + 8 + qb
-        for k in range(4):
-            g.I(f"v_mul_f32 {vreg(V_L + 4 * qb + k)}, {vreg(V_L + 4 * qb + k)}, {vreg(f)}")
+        d, f = V_T + qb, V_T + 2 + qb
+        g.I(f"v_mul_f32 {vreg(V_LACC + 16 * qb)}, {vreg(V_LACC + 16 * qb)}, {vreg(f)}")      # only register 0 is read at the end
         for r in range(16):
             g.I(f"v_sub_f32 {vreg(V_NM + 16 * qb + r)}, {vreg(V_NM + 16 * qb + r)}, {vreg(d)}")
         for kb in range(2):
@@ -328,6 +321,7 @@ def ret_dispatch(g: Gen, ret_labels):
 # ---- the kernel -------------------------------------------------------------------------------------------------------
 def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str:
     global DMA, PFX, DIAG
+    assert dma == "buffer"
     DMA, PFX, DIAG = dma, prefix, diag
     g = Gen()
     I = g.I
@@ -341,18 +335,12 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     I(f"s_mov_b32 {sreg(S_THR)}, {hex(f32bits(THR))}")
     I(f"s_mov_b32 {sreg(S_NINF)}, 0xff800000")
     I(f"s_lshl_b32 {sreg(S_STEP)}, {sreg(S_LDK)}, 6")                       # bytes per 64-key tile
-    if DMA == "buffer":
-        # buffer descriptors: base, stride 0, num_records, raw dword format (0x00020000 = the compiler's make_buffer_rsrc flags)
-        for rs, base in ((S_KRS, S_K), (S_VRS, S_V)):
-            I(f"s_mov_b32 {sreg(rs)}, {sreg(base)}")
-            I(f"s_and_b32 {sreg(rs + 1)}, {sreg(base + 1)}, 0xffff")
-            I(f"s_mov_b32 {sreg(rs + 2)}, {sreg(S_NREC)}")
-            I(f"s_mov_b32 {sreg(rs + 3)}, 0x00020000")
-    else:
-        for rs, base in ((S_KRS, S_K), (S_VRS, S_V)):
-            I(f"s_mov_b64 {sreg(rs, 2)}, {sreg(base, 2)}")
-            I(f"s_mov_b32 {sreg(rs + 2)}, 0")
-        I(f"s_sub_u32 {sreg(S_NTM1)}, {sreg(S_NT)}, 1")
+    # buffer descriptors: base, stride 0, num_records, raw dword format (0x00020000 = the compiler's make_buffer_rsrc flags)
+    for rs, base in ((S_KRS, S_K), (S_VRS, S_V)):
+        I(f"s_mov_b32 {sreg(rs)}, {sreg(base)}")
+        I(f"s_and_b32 {sreg(rs + 1)}, {sreg(base + 1)}, 0xffff")
+        I(f"s_mov_b32 {sreg(rs + 2)}, {sreg(S_NREC)}")
+        I(f"s_mov_b32 {sreg(rs + 3)}, 0x00020000")
     # LDS-DMA destination of this wave's pieces: slot + (4 wave + i) KiB
     I(f"s_lshl_b32 {sreg(S_KM0)}, {sreg(S_WAVE)}, 12")
     I(f"s_mov_b32 {sreg(S_VM0)}, {sreg(S_KM0)}")
@@ -375,13 +363,6 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
         I(f"v_lshlrev_b32 {vreg(t_x)}, 4, {vreg(t_x)}")
         I(f"v_mul_lo_u32 {vreg(V_DV + i)}, {vreg(t_key)}, {sreg(S_LDK)}")
         I(f"v_add_u32 {vreg(V_DV + i)}, {vreg(V_DV + i)}, {vreg(t_x)}")
-        if DMA == "global":                          # the same two offsets with the row clamped to last_valid - 1 (the swizzle still follows the LDS row)
-            I(f"s_sub_u32 {sreg(S_T1)}, {sreg(S_LASTV)}, 1")
-            I(f"v_min_u32 {vreg(t_key + 2)}, {sreg(S_T1)}, {vreg(t_key)}")
-            I(f"v_sub_u32 {vreg(t_key + 2)}, {vreg(t_key)}, {vreg(t_key + 2)}")           # rows to step back
-            I(f"v_mul_lo_u32 {vreg(t_key + 2)}, {vreg(t_key + 2)}, {sreg(S_LDK)}")
-            I(f"v_sub_u32 {vreg(V_DKL + i)}, {vreg(V_DK + i)}, {vreg(t_key + 2)}")
-            I(f"v_sub_u32 {vreg(V_DVL + i)}, {vreg(V_DV + i)}, {vreg(t_key + 2)}")
     # prologue staging: K(0..3), V(0..2)
     for t in range(4):
         for op in dma_pieces("K", t) + dma_step("K"):
@@ -436,8 +417,10 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     # O = 0, l = 0 while the loads fly
     for r in range(128):
         I(f"v_accvgpr_write_b32 {areg(A_O + r)}, 0")
-    for k in range(8):
-        I(f"v_mov_b32 {vreg(V_L + k)}, 0")
+    for k in range(32):
+        I(f"v_mov_b32 {vreg(V_LACC + k)}, 0")
+    for k in range(4):
+        I(f"v_mov_b32 {vreg(V_ONES + k)}, 0x3f803f80")
     I("s_waitcnt vmcnt(0)")                           # Q, and every staged tile of the prologue
     for qb in range(2):
         for ks in range(8):
@@ -498,13 +481,13 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
         y = u & 1                                     # the last tile's index is congruent to u mod 4
         for op in finish_ops(y):
             I(op)
-        for n in range(8):
+        for n in range(NVF):
             for op in v_frag_reads(n, u):
                 I(op)
         fillers = []
-        for n in range(8, 16):
+        for n in range(NVF, 16):
             for k, op in enumerate(v_frag_reads(n, u)):
-                fillers.append((2 * (n - 8) + 1.2 + 0.1 * k, op))
+                fillers.append((pv_index(n - NVF) + 1.9 + 0.02 * k, op))
         g.phase(pv_mfmas(y), fillers)
         I("s_branch LL_EPILOGUE")
     # ================= epilogue =================
@@ -584,9 +567,9 @@ def gen_tile(g: Gen, u: int):
     placed = [(0.3 + span * t / (tmax + 1) + 0.001 * k, op) for k, (t, op) in enumerate(fin)]
     fillers = [(p_, op) for p_, op in placed if p_ < 32]
     fin_b = [(p_ - 32, op) for p_, op in placed if p_ >= 32]
-    for n in range(5):                                # fragments 0..4 of V(i-1): ten gaps ahead of their first use
+    for n in range(NVF):                              # the first ring-full of V(i-1) fragments, at the end of A_i
         for k, op in enumerate(v_frag_reads(n, u - 1)):
-            fillers.append((22 + 2 * n + 0.9 + 0.05 * k, op))
+            fillers.append((32 - 2 * (NVF - n) + 0.9 + 0.05 * k, op))
     dma_a = KNOB("DMA_IN_A", 0)
     if dma_a and not KNOB("NO_DMA", 0):
         fillers += spread(dma_ops(u + 3, u + 2), 1.4, 30.5)
@@ -601,16 +584,16 @@ def gen_tile(g: Gen, u: int):
     I(f"s_mov_b32 {sreg(S_RET)}, {mask_rets(x).index(f'LL_MASK_RET_{u}')}")
     I(f"s_branch LL_MASK_{x}")
     g.L(f"LL_MASK_RET_{u}")
-    # ---- B_i: O^T += V(i-1)^T P(i-1)^T  ||  start(i)  ||  K(i+1) -> AGPRs, V(i-1) fragments 5..15  ||  LDS-DMA K(i+3), V(i+2)
+    # ---- B_i: O^T += V(i-1)^T P(i-1)^T + row sums  ||  start(i)  ||  K(i+1) -> AGPRs, V(i-1) fragments NVF..15  ||  LDS-DMA K(i+3), V(i+2)
     fillers = []
     for k, op in enumerate([] if KNOB("NO_KREAD", 0) else k_frag_reads(u + 1)):
         fillers.append((0.5 + k * KNOB("KREAD_STEP", 0.95), op))
-    for n in range(5, 16):
+    for n in range(NVF, 16):                          # fragment n re-uses the ring slot of fragment n - NVF: read it right after that one's MFMAs
         for k, op in enumerate(v_frag_reads(n, u - 1)):
-            fillers.append((2 * n - 10 + 0.9 + 0.05 * k, op))
-    fillers += spread(start_ops(x)[(-3 if KNOB("NO_START", 0) else 0):], 3.2, KNOB("START_END", 22.0))
+            fillers.append((pv_index(n - NVF) + 1.9 + 0.02 * k, op))
+    fillers += spread(start_ops(x)[(-3 if KNOB("NO_START", 0) else 0):], 3.2, KNOB("START_END", 27.0))
     if not dma_a and not KNOB("NO_DMA", 0):
-        fillers += spread(dma_ops(u + 3, u + 2), 16.4, 31.5)
+        fillers += spread(dma_ops(u + 3, u + 2), 20.4, 39.5)
     fillers += fin_b
     g.phase(pv_mfmas(y), fillers)
     # rescale decision (after every P.V of tile i-1 has issued), then the tile barrier
@@ -630,23 +613,10 @@ def gen_epilogue(g: Gen):
     o[qb][db].  v_permlane32_swap of the packed words of g4 = k (vdst) and k + 1 (src) gives every lane 16 contiguous bytes
     (d = 32 db + 8 (k + h) .. +7): 8 x 16-byte stores per q-block (T21)."""
     I = g.I
+    for qb in range(2):                               # every register of LACC[qb] holds the lane's query's row sum: take register 0
+        I(f"v_rcp_f32 {vreg(V_LACC + 16 * qb)}, {vreg(V_LACC + 16 * qb)}")
     for qb in range(2):
-        l = V_L + 4 * qb
-        I(f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(l + 1)}")
-        I(f"v_add_f32 {vreg(l + 2)}, {vreg(l + 2)}, {vreg(l + 3)}")
-    for qb in range(2):
-        l = V_L + 4 * qb
-        I(f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(l + 2)}")
-    for qb in range(2):
-        I(f"v_mov_b32 {vreg(V_T + qb)}, {vreg(V_L + 4 * qb)}")
-    I("s_nop 0")
-    for qb in range(2):
-        I(f"v_permlane32_swap_b32 {vreg(V_L + 4 * qb)}, {vreg(V_T + qb)}")
-    for qb in range(2):
-        I(f"v_add_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}, {vreg(V_T + qb)}")
-        I(f"v_rcp_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}")
-    for qb in range(2):
-        inv = V_L + 4 * qb
+        inv = V_LACC + 16 * qb
         # output row address: O base + row * ldo + (4 h elements -> the swap moves it to 8 (k + h)) ; 64-bit
         I(f"v_mul_lo_u32 {vreg(V_T + 2)}, {vreg(V_ROW + qb)}, {sreg(S_LDO)}")
         I(f"v_lshl_add_u32 {vreg(V_T + 2)}, {vreg(V_H)}, 4, {vreg(V_T + 2)}")            # + 16 h bytes

@@ -19,10 +19,9 @@ import attn_asm_gen as G          # noqa: E402
 import gfx950_emu as E            # noqa: E402
 
 
-@pytest.fixture(scope="module", params=["buffer", "global"])
-def kernel_text(request):
-    """both staging forms: buffer_load ... lds through a shrinking descriptor, and global_load_lds with clamped tiles / rows"""
-    return G.generate(request.param, "LL" + request.param[0].upper())
+@pytest.fixture(scope="module")
+def kernel_text():
+    return G.generate("buffer", "LLB")
 
 
 def bf16_bits(x):

@@ -54,8 +54,6 @@ def test_flash_attn_production_grids(Lq):
         _tuning("attn_xcd", 0)
         got0 = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_xcd", 1)
-        _tuning("attn_asm", 2)                 # the same kernel with global_load_lds staging
-        asm_g = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_asm", 0)                 # round 1-2's kernel: 8 waves x 32 rows, ping-pong wave groups
         pipe = ops.flash_attn(q, k, v, [(0, Lk)])
         _tuning("attn_xcd", 0)
@@ -77,7 +75,6 @@ def test_flash_attn_production_grids(Lq):
         _tuning("attn_mfma16", 0)
         _tuning("attn_asm", 1)
     assert torch.equal(got, got0) and torch.equal(sk, sk0) and torch.equal(pipe, pipe0), "XCD-aware workgroup placement must not change a single bit"
-    assert torch.equal(got, asm_g), "the two staging forms of the generated kernel stage the same bytes"
     # every element: a wrong (head, q-tile) mapping or a dropped key tile is an O(1) error, far above two kernels' rounding
     d = (got.float() - plain.float()).abs()
     assert d.max().item() < 8e-3, d.max().item()
