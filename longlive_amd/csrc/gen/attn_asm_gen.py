@@ -52,18 +52,24 @@ DIAG = False                                 # diagnostic build only (tools/attn
 S_DBG, S_WG = 56, 58
 import os as _os
 KNOB = lambda name, default: type(default)(_os.environ.get("ASM_" + name, default))    # schedule experiments (tools/attn_asm_diag)
+LSUM = KNOB("LSUM", 0)                       # 1: row sums by the matrix pipe (ones-MFMA into LACC); 0: by v_add_f32 into 4 partials per q-block
+ADD_LATE = KNOB("ADD_LATE", 0)               # LSUM = 0: the adds of the elements whose registers survive the in-place pack (registers
+                                             # 8..15 of every score tile) are issued in phase B instead of phase A
 S_TS, S_ACC = 60, 64                         # last stamp s[60:61]; sums s[64:65] A, s[66:67] B, s[68:69] wait+barrier, s[70:71] whole loop
 
 A_O, A_Q, A_K = 0, 128, 192
-V_S, V_NM, V_VF = 0, 128, 160                # S buffers 0..127, -m tiles 128..159, ring of 4 V^T fragments 160..175
-NVF = 4
-V_LACC = 176                                  # row-sum accumulators LACC[qb][0:15] 176..207: D of the ones-MFMA (every register of a lane = its query's sum)
-V_KOFF, V_VOFF, V_DK, V_DV = 208, 216, 220, 224      # 8 K-read offsets, 4 V-read offsets, 4 + 4 DMA source offsets
-V_ONES = 228                                  # 228..231: bf16 1.0 in every element (A operand of the row-sum MFMA)
-V_MX = 232                                    # mx[qb] tile max (cross-half) -> 232, 233
-V_ROW = 234                                   # per-qb row index within the workgroup -> 234, 235
-V_LANE, V_R, V_H = 236, 237, 238
-V_T = 240                                     # temporaries 240..253
+NVF = KNOB("NVF", 4 if LSUM else 8)          # ring of V^T fragments (4 registers each); the row-sum MFMA form needs the room for LACC
+V_S, V_NM, V_VF = 0, 128, 160                # S buffers 0..127, -m tiles 128..159, V^T fragment ring from 160
+_next = V_VF + 4 * NVF
+V_L = V_LACC = _next                          # LSUM = 0: l[qb][4] partial row sums (8 registers); LSUM = 1: LACC[qb][0:15], D of the row-sum
+_next += 32 if LSUM else 8                    # MFMA (every register of a lane = its query's sum)
+V_KOFF, V_VOFF, V_DK, V_DV = _next, _next + 8, _next + 12, _next + 16      # 8 K-read offsets, 4 V-read offsets, 4 + 4 DMA source offsets
+V_ONES = _next + 20                           # 4 registers of bf16 1.0 (A operand of the row-sum MFMA)
+V_MX = _next + 24                             # mx[qb]: the tile's row max (both halves)
+V_ROW = _next + 26                            # per-qb row index within the workgroup
+V_LANE, V_R, V_H = _next + 28, _next + 29, _next + 30
+V_T = _next + 32                              # 14 temporaries
+assert V_T + 14 <= 256, V_T
 V_TID = 0                                     # input: workitem id
 
 KSLOT = lambda s: 16384 * (s & 3)             # LDS: K ring at 0, V ring at 64 KiB
@@ -146,7 +152,7 @@ def pv_mfmas(y):
             for qb in range(2):
                 o = areg(A_O + 64 * qb + 16 * db, 16)
                 out.append(f"v_mfma_f32_32x32x16_bf16 {o}, {vreg(V_VF + 4 * (n % NVF), 4)}, {vreg(P_f(y, qb, kstep), 4)}, {o}")
-        for qb in range(2):
+        for qb in range(2 if LSUM else 0):
             l = vreg(V_LACC + 16 * qb, 16)
             out.append(f"v_mfma_f32_32x32x16_bf16 {l}, {vreg(V_ONES, 4)}, {vreg(P_f(y, qb, kstep), 4)}, {l}")
     return out
@@ -154,7 +160,7 @@ def pv_mfmas(y):
 
 def pv_index(n):
     """index of the first of the two MFMAs that consume V^T fragment n"""
-    return 10 * (n >> 2) + 2 * (n & 3)
+    return (10 if LSUM else 8) * (n >> 2) + 2 * (n & 3)
 
 
 def v_frag_reads(n, vslot):
@@ -178,7 +184,7 @@ def finish_ops(y, with_pos=False):
     """exp2 and pack of S(y) -> P in place (the row sum is taken by the matrix pipe: pv_mfmas).  Order = the order PV consumes the fragments: k-step, then qb.  Emitted as a
     software pipeline (exp of element n, add of element n - DA, pack of a pair DC back) so that no instruction depends on its
     near predecessors.  with_pos: (element index the op belongs to, text) so that the caller can place ops by deadline."""
-    DC = KNOB("FIN_DC", 3)
+    DC = KNOB("FIN_DC", 5 if not LSUM else 3)
     elems = []
     for kstep in range(4):
         for qb in range(2):
@@ -191,6 +197,10 @@ def finish_ops(y, with_pos=False):
     for t in range(n + DC + 2):
         if t < n:
             ops.append((t, (f"v_mov_b32 {vreg(elems[t][1])}, {vreg(elems[t][1])}" if noexp else f"v_exp_f32 {vreg(elems[t][1])}, {vreg(elems[t][1])}")))
+        if not LSUM and 2 <= t < n + 2:
+            qb, r, _, j = elems[t - 2]
+            late = ADD_LATE and (r & 15) >= 8
+            ops.append((t if not late else 1000 + t, f"v_add_f32 {vreg(V_L + 4 * qb + (j & 3))}, {vreg(V_L + 4 * qb + (j & 3))}, {vreg(r)}"))
         if t >= DC and (t - DC) % 2 == 0 and t - DC < n:
             qb, r0, dst, j = elems[t - DC]
             ops.append((t, f"v_cvt_pk_bf16_f32 {vreg(dst)}, {vreg(r0)}, {vreg(r0 + 1)}"))
@@ -277,7 +287,11 @@ def gen_rescale(g: Gen, x: int, ret_labels):
         g.I(f"v_exp_f32_e64 {vreg(f)}, -{vreg(d)}")
     for qb in range(2):
         d, f = V_T + qb, V_T + 2 + qb
-        g.I(f"v_mul_f32 {vreg(V_LACC + 16 * qb)}, {vreg(V_LACC + 16 * qb)}, {vreg(f)}")      # only register 0 is read at the end
+        if LSUM:
+            g.I(f"v_mul_f32 {vreg(V_LACC + 16 * qb)}, {vreg(V_LACC + 16 * qb)}, {vreg(f)}")      # only register 0 is read at the end
+        else:
+            for k in range(4):
+                g.I(f"v_mul_f32 {vreg(V_L + 4 * qb + k)}, {vreg(V_L + 4 * qb + k)}, {vreg(f)}")
         for r in range(16):
             g.I(f"v_sub_f32 {vreg(V_NM + 16 * qb + r)}, {vreg(V_NM + 16 * qb + r)}, {vreg(d)}")
         for kb in range(2):
@@ -417,10 +431,11 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     # O = 0, l = 0 while the loads fly
     for r in range(128):
         I(f"v_accvgpr_write_b32 {areg(A_O + r)}, 0")
-    for k in range(32):
+    for k in range(32 if LSUM else 8):
         I(f"v_mov_b32 {vreg(V_LACC + k)}, 0")
-    for k in range(4):
-        I(f"v_mov_b32 {vreg(V_ONES + k)}, 0x3f803f80")
+    if LSUM:
+        for k in range(4):
+            I(f"v_mov_b32 {vreg(V_ONES + k)}, 0x3f803f80")
     I("s_waitcnt vmcnt(0)")                           # Q, and every staged tile of the prologue
     for qb in range(2):
         for ks in range(8):
@@ -563,10 +578,12 @@ def gen_tile(g: Gen, u: int):
     # ---- A_i: S(i) = K(i) Q^T  ||  finish(i-1)  ||  first V(i-1) fragments
     fin = finish_ops(y, with_pos=True)
     span = KNOB("FIN_SPAN", 31.0)                    # finish(i-1) is spread over this many MFMA gaps from the start of A_i; beyond 32 it
+    late = [op for t, op in fin if t >= 1000]        # row-sum adds deferred to phase B (ADD_LATE)
+    fin = [(t, op) for t, op in fin if t < 1000]
     tmax = max([t for t, _ in fin] + [0])            # runs on into B_i, ahead of the P.V k-steps that consume it (k-step k starts at B gap 8 k)
     placed = [(0.3 + span * t / (tmax + 1) + 0.001 * k, op) for k, (t, op) in enumerate(fin)]
     fillers = [(p_, op) for p_, op in placed if p_ < 32]
-    fin_b = [(p_ - 32, op) for p_, op in placed if p_ >= 32]
+    fin_b = [(p_ - 32, op) for p_, op in placed if p_ >= 32] + spread(late, KNOB("LATE_LO", 1.3), KNOB("LATE_HI", 30.0))
     for n in range(NVF):                              # the first ring-full of V(i-1) fragments, at the end of A_i
         for k, op in enumerate(v_frag_reads(n, u - 1)):
             fillers.append((32 - 2 * (NVF - n) + 0.9 + 0.05 * k, op))
@@ -613,10 +630,26 @@ def gen_epilogue(g: Gen):
     o[qb][db].  v_permlane32_swap of the packed words of g4 = k (vdst) and k + 1 (src) gives every lane 16 contiguous bytes
     (d = 32 db + 8 (k + h) .. +7): 8 x 16-byte stores per q-block (T21)."""
     I = g.I
-    for qb in range(2):                               # every register of LACC[qb] holds the lane's query's row sum: take register 0
-        I(f"v_rcp_f32 {vreg(V_LACC + 16 * qb)}, {vreg(V_LACC + 16 * qb)}")
+    if LSUM:
+        for qb in range(2):                           # every register of LACC[qb] holds the lane's query's row sum: take register 0
+            I(f"v_rcp_f32 {vreg(V_LACC + 16 * qb)}, {vreg(V_LACC + 16 * qb)}")
+    else:
+        for qb in range(2):
+            l = V_L + 4 * qb
+            I(f"v_add_f32 {vreg(l)}, {vreg(l)}, {vreg(l + 1)}")
+            I(f"v_add_f32 {vreg(l + 2)}, {vreg(l + 2)}, {vreg(l + 3)}")
+        for qb in range(2):
+            I(f"v_add_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb + 2)}")
+        for qb in range(2):
+            I(f"v_mov_b32 {vreg(V_T + qb)}, {vreg(V_L + 4 * qb)}")
+        I("s_nop 0")
+        for qb in range(2):                           # the other half of the wave holds the other 32 keys of every tile
+            I(f"v_permlane32_swap_b32 {vreg(V_L + 4 * qb)}, {vreg(V_T + qb)}")
+        for qb in range(2):
+            I(f"v_add_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}, {vreg(V_T + qb)}")
+            I(f"v_rcp_f32 {vreg(V_L + 4 * qb)}, {vreg(V_L + 4 * qb)}")
     for qb in range(2):
-        inv = V_LACC + 16 * qb
+        inv = (V_LACC + 16 * qb) if LSUM else (V_L + 4 * qb)
         # output row address: O base + row * ldo + (4 h elements -> the swap moves it to 8 (k + h)) ; 64-bit
         I(f"v_mul_lo_u32 {vreg(V_T + 2)}, {vreg(V_ROW + qb)}, {sreg(S_LDO)}")
         I(f"v_lshl_add_u32 {vreg(V_T + 2)}, {vreg(V_H)}, 4, {vreg(V_T + 2)}")            # + 16 h bytes
