@@ -333,3 +333,49 @@ def test_config5_int8_long_run_property(real30):
     _check_long(P, lat, cfg, T)
     if T == 960:
         assert (P.kv_cache1[0]["global_end_index"], P.kv_cache1[0]["local_end_index"]) == (1497600, 18720)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_batch2_throughput_mode_is_bit_identical_to_two_streams(real30):
+    """Throughput mode of BASELINE config 5 (`num_samples` prompts per GPU, configs/longlive_inference.yaml:23, inference.py:193-195):
+    TWO independent prompt streams batched through one forward (B = 2: every GEMM sees M = 9360 and reads its weights once, the
+    self-attention launch has 456 workgroups).  Real shape, 30 layers, 12 latent frames (4 AR blocks: direct insert, roll and the
+    full 12-frame window).  The batched latents must equal the two streams run one at a time BIT FOR BIT: no kernel may mix rows of
+    different samples, and a row's arithmetic may not depend on where its tile falls.  (The B = 1 runs take the unsplit FFN2 here:
+    the split-K form -- not eligible at M = 9360 -- sums its two K-halves in another order.)"""
+    from longlive_amd.pipeline import CausalInferencePipeline
+    cfg, gen = real30
+    T = 12
+    noises = [synth.synth_noise(cfg, T, seed=s, device=DEV) for s in (0, 1)]
+    prompts = [synth.synth_prompt_embeds(cfg, seed=11 + s, device=DEV) for s in (0, 1)]
+
+    class PerSampleRandn:                                 # re-noise source: sample b of a batch draws what stream b draws alone
+        def __init__(self, streams):
+            self.streams, self.i = streams, 0
+
+        def __call__(self, like):                          # like: [B * F, 16, h, w]
+            per = like.shape[0] // len(self.streams)
+            x = torch.cat([synth.hash_normal(77 + s, f"renoise.{self.i}", (per,) + tuple(like.shape[1:])).to(like.dtype) for s in self.streams])
+            self.i += 1
+            return x.to(like.device)
+
+    def run(noise, prompt, streams):
+        P = CausalInferencePipeline(_pipe_args(), DEV, generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": prompt})
+        P.randn_like = PerSampleRandn(streams)
+        _, lat = P.inference(noise, ["p"] * noise.shape[0], return_latents=True)
+        return lat
+
+    split = gen.model.ffn2_splitk
+    try:
+        gen.model.ffn2_splitk = False
+        singles = [run(noises[s], prompts[s], [s]) for s in (0, 1)]
+        both = run(torch.cat(noises), torch.cat(prompts), [0, 1])
+    finally:
+        gen.model.ffn2_splitk = split
+    assert both.shape == (2, T, 16, 60, 104) and torch.isfinite(both.float()).all()
+    assert not torch.equal(singles[0], singles[1])
+    for s in (0, 1):
+        assert torch.equal(both[s:s + 1], singles[s]), f"sample {s}: {(both[s:s + 1].float() - singles[s].float()).abs().max().item()}"
+    # and against the default B = 1 path (split-K FFN2): same stream up to the order of one fp32 sum per FFN2 output
+    ref = run(noises[0], prompts[0], [0])
+    assert rel_l2(both[0:1], ref) < 2e-2

@@ -13,11 +13,15 @@ pass() {
   name=$1; shift
   timeout -k 10 420 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1
   rc=$?
-  if [ $rc -ge 124 ]; then echo "pass $name killed (rc $rc): stopping"; exit $rc; fi
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name timed out / killed (rc $rc): stopping"; exit $rc; fi
   if [ $rc -ne 0 ]; then echo "pass $name failed (rc $rc), skipped"; tail -3 "$OUT/$name.log"; else echo "pass $name ok: $(grep -o '"value": [0-9.]*' "$OUT/$name.log" | head -1)"; fi
 }
 pass trace --kernel-trace
-pass sq1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+# a python / torch process under --pmc died in rocprofv3's dispatch hook at its FIRST kernel with 8 SQ counters (round 3, r03b:
+# SIGSEGV, rc 139); smaller groups are tried first, and a probe of a trivial torch program says whether any group can work at all
+timeout -k 10 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/probe" -- python3 -c "import torch; x = torch.ones(1 << 20, device='cuda'); print(float((x + 1).sum()))" > "$OUT/probe.log" 2>&1; echo "probe (trivial torch program under --pmc GRBM_GUI_ACTIVE): rc $?"
+pass sq1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE
+pass sq2 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 pass tcc_rd --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum GRBM_GUI_ACTIVE
 pass tcc_wr --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum GRBM_GUI_ACTIVE
 echo "done: $OUT"

@@ -85,10 +85,13 @@ def main():
     tr = load_trace(os.path.join(out, "trace"))
     trace, span = tr if tr else ({}, None)
     tables = {}
-    for name in ("sq1", "tcc_rd", "tcc_wr"):
+    for name in ("sq1", "sq2", "tcc_rd", "tcc_wr"):
         lc = load_counters(os.path.join(out, name))
         if lc:
             tables[name] = group_means(*lc)
+    if "sq2" in tables:                               # wave-cycle shares come from their own pass: merge per kernel
+        for g_, c_ in tables["sq2"].items():
+            tables.setdefault("sq1", {}).setdefault(g_, {}).update({k: v for k, v in c_.items() if k not in ("GRBM_GUI_ACTIVE", "_n") or k not in tables["sq1"].get(g_, {})})
     groups = sorted(trace, key=lambda g: -trace[g][0] * trace[g][1]) if trace else sorted(tables.get("sq1", {}))
     total_us = sum(trace[g][0] * trace[g][1] for g in trace) if trace else None
     rec = {"steady_window_ms": span, "kernels": []}
