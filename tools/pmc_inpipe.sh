@@ -1,6 +1,6 @@
 #!/bin/bash
-# In-pipeline counters: rocprofv3 --pmc passes over bench.py itself (the program directly after `--`, no tracing flags beside
-# --pmc), so that MFMA utilisation, wave-cycle shares and fabric traffic are stated for the regime the headline is measured in
+# In-pipeline counters: rocprofv3 --pmc passes (the program directly after `--`, no tracing flags beside --pmc) over the model's launch
+# sequence replayed by tools/kbench layerseq (bench.py itself under --pmc segfaults inside rocprofv3: see the probe below), so that MFMA utilisation, wave-cycle shares and fabric traffic are stated for the regime the headline is measured in
 # (kernels running back to back inside the 30-layer forward, the clock the pipeline holds), next to the tools/kbench figures.
 # Run ON the GPU box:   bash tools/pmc_inpipe.sh <outdir>     then   python tools/pmc_inpipe_summary.py <outdir> --md ... --json ...
 set -u
@@ -8,13 +8,13 @@ OUT=${1:-gpurun_out/pmc_inpipe}
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-ARGS="bench.py --steps 2 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer"
+ARGS="layerseq 300"       # tools/kbench layerseq: one steady-state layer's 13 launches in model order, 300 layers = 2 AR blocks
 pass() {
   name=$1; shift
-  timeout -k 10 420 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1
+  timeout -k 10 420 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- ./tools/kbench $ARGS > "$OUT/$name.log" 2>&1
   rc=$?
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "pass $name timed out / killed (rc $rc): stopping"; exit $rc; fi
-  if [ $rc -ne 0 ]; then echo "pass $name failed (rc $rc), skipped"; tail -3 "$OUT/$name.log"; else echo "pass $name ok: $(grep -o '"value": [0-9.]*' "$OUT/$name.log" | head -1)"; fi
+  if [ $rc -ne 0 ]; then echo "pass $name failed (rc $rc), skipped"; tail -3 "$OUT/$name.log"; else echo "pass $name ok: $(grep layerseq "$OUT/$name.log" | head -1)"; fi
 }
 pass trace --kernel-trace
 # a python / torch process under --pmc died in rocprofv3's dispatch hook at its FIRST kernel with 8 SQ counters (round 3, r03b:

@@ -7,9 +7,9 @@ by (name, grid size); per group the mean over its dispatches of
 
   duration            kernel-trace pass (un-counted run), End - Start
   cycles              GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the counter over the 8 XCDs)                 -- of the COUNTED run
-  implied clock       cycles / duration of the SAME counted run is not available (counter passes carry no timestamps in csv), so
-                      the clock is quoted as cycles(counted) / duration(traced): reads HIGH on launches shorter than ~0.3 ms
-                      (MI355X_MICROARCH.md, DVFS give-back) and profiled passes run ~3 % slower clocks than un-profiled ones
+  implied clock       cycles / duration of the same counted dispatches (the counter csv carries their timestamps): reads HIGH on
+                      launches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back); counted passes serialise dispatches and
+                      run ~3 % lower clocks than un-profiled ones
   MFMA utilisation    SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles); busy cycles per MFMA printed as a check (32 / 16)
   wave-cycle shares   SQ_WAIT_ANY (parked at a wait/barrier), SQ_WAIT_INST_ANY (issue-stalled), SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
   fabric bytes        2 x FETCH_SIZE + WRITE_SIZE from TCC_EA0_RDREQ / _32B / TCC_BUBBLE and TCC_EA0_WRREQ / _64B (gfx950: FETCH_SIZE
@@ -40,8 +40,10 @@ def load_counters(d):
     meta = {}
     for r in csv.DictReader(open(files[0])):
         i = int(r["Dispatch_Id"])
-        meta[i] = (short(r["Kernel_Name"]), int(r.get("Grid_Size", 0) or 0))
+        meta[i] = short(r["Kernel_Name"])
         per[i][r["Counter_Name"]] = per[i].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        if r.get("End_Timestamp") and r.get("Start_Timestamp"):       # the counted run's own duration of this dispatch
+            per[i]["_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
     return per, meta
 
 
@@ -68,7 +70,7 @@ def load_trace(d):
     rows = rows[len(rows) - len(rows) // 3:]
     acc = defaultdict(list)
     for r in rows:
-        acc[(short(r["Kernel_Name"]), int(r.get("Grid_Size", 0) or 0))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+        acc[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
     span = (max(int(r["End_Timestamp"]) for r in rows) - min(int(r["Start_Timestamp"]) for r in rows)) * 1e-6
     return {g: (sum(v) / len(v), len(v)) for g, v in acc.items()}, span
 
@@ -95,17 +97,18 @@ def main():
     groups = sorted(trace, key=lambda g: -trace[g][0] * trace[g][1]) if trace else sorted(tables.get("sq1", {}))
     total_us = sum(trace[g][0] * trace[g][1] for g in trace) if trace else None
     rec = {"steady_window_ms": span, "kernels": []}
-    lines = ["| kernel (grid) | launches | avg us (trace) | share | MFMA util | cyc/MFMA | implied clock GHz | wait / stall / active | fabric MB per launch |",
+    lines = ["| kernel | launches | avg us (trace) | share | MFMA util | cyc/MFMA | implied clock GHz | wait / stall / active | fabric MB per launch |",
              "|---|---|---|---|---|---|---|---|---|"]
     for g in groups:
         us, n = trace.get(g, (None, 0))
-        d = {"kernel": g[0], "grid": g[1], "launches_in_window": n, "avg_us": us}
+        d = {"kernel": g, "launches_in_window": n, "avg_us": us}
         sq = tables.get("sq1", {}).get(g)
         if sq and sq.get("GRBM_GUI_ACTIVE"):
             cyc = sq["GRBM_GUI_ACTIVE"] / 8
             d["cycles_counted"] = cyc
-            if us:
-                d["implied_clock_ghz"] = cyc / (us * 1e3)
+            if sq.get("_us"):
+                d["avg_us_counted"] = sq["_us"]
+                d["implied_clock_ghz"] = cyc / (sq["_us"] * 1e3)         # cycles and duration of the SAME (counted) dispatches
             if sq.get("SQ_INSTS_MFMA"):
                 d["mfma_util"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc)
                 d["busy_cycles_per_mfma"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / sq["SQ_INSTS_MFMA"]
@@ -123,8 +126,8 @@ def main():
         rec["kernels"].append(d)
         f = lambda x, fmt: "-" if x is None else fmt % x
         share = None if not (us and total_us) else us * n / total_us
-        lines.append("| `%s` (%d) | %d | %s | %s | %s | %s | %s | %s | %s |" % (
-            g[0][:70], g[1], n, f(us, "%.1f"), f(share and 100 * share, "%.1f %%"), f(d.get("mfma_util") and 100 * d["mfma_util"], "%.1f %%"),
+        lines.append("| `%s` | %d | %s | %s | %s | %s | %s | %s | %s |" % (
+            g[:70], n, f(us, "%.1f"), f(share and 100 * share, "%.1f %%"), f(d.get("mfma_util") and 100 * d["mfma_util"], "%.1f %%"),
             f(d.get("busy_cycles_per_mfma"), "%.1f"), f(d.get("implied_clock_ghz"), "%.2f"),
             "-" if "SQ_WAIT_ANY_share" not in d else "%.0f / %.0f / %.0f %%" % (100 * d["SQ_WAIT_ANY_share"], 100 * d["SQ_WAIT_INST_ANY_share"], 100 * d["SQ_ACTIVE_INST_ANY_share"]),
             f(d.get("fabric_bytes_per_launch") and d["fabric_bytes_per_launch"] / 1e6, "%.1f")))
