@@ -41,7 +41,7 @@ S_ROWS, S_NT, S_LASTV, S_C, S_NREC = 19, 20, 21, 22, 23
 S_KRS, S_VRS = 24, 28                        # buffer descriptors s[24:27], s[28:31]
 S_WAVE, S_I, S_STEP, S_T0, S_T1, S_T2, S_T3 = 32, 33, 34, 36, 37, 38, 39
 S_M0, S_M1 = 40, 42                          # 64-bit lane masks
-S_THR, S_NINF, S_RET, S_KM0, S_VM0 = 48, 49, 50, 52, 53
+S_THR, S_NINF, S_RET, S_KM0, S_VM0, S_MASKI = 48, 49, 50, 52, 53, 54
 THR = 8.0                                    # lazy-max threshold in log2 units (P <= 2^8 between rescales)
 DMA = "buffer"                               # buffer_load ... lds through a descriptor whose num_records shrinks tile by tile: rows past the key
                                              # range read as zeros, tiles past the end are all zeros (a global_load_lds form with clamped tiles /
@@ -248,9 +248,16 @@ def start_ops(x):
 
 
 def dma_pieces(which, slot):
-    """this wave's four 1-KiB LDS-DMA pieces of one K or V tile into ring slot `slot`"""
+    """this wave's four 1-KiB LDS-DMA pieces of one K or V tile into ring slot `slot`.  M0_OFFS = 1: ONE m0 write per tensor, the
+    pieces addressed by the instruction's 12-bit offset, which moves the LDS destination AND the source address by 1024 i -- the
+    source offsets V_DK / V_DV are pre-biased by -1024 i (the range check sees voffset + offset: unchanged)."""
     ops = []
     m0b, ring, off, rs = (S_KM0, KSLOT, V_DK, S_KRS) if which == "K" else (S_VM0, VSLOT, V_DV, S_VRS)
+    if KNOB("M0_OFFS", 0):
+        ops.append(f"s_add_u32 m0, {sreg(m0b)}, {ring(slot)}")
+        for i in range(4):
+            ops.append(f"buffer_load_dwordx4 {vreg(off + i)}, {sreg(rs, 4)}, 0 offen" + (f" offset:{1024 * i}" if i else "") + " lds")
+        return ops
     for i in range(4):
         ops.append(f"s_add_u32 m0, {sreg(m0b)}, {ring(slot) + 1024 * i}")
         ops.append(f"buffer_load_dwordx4 {vreg(off + i)}, {sreg(rs, 4)}, 0 offen lds")
@@ -349,6 +356,9 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     I(f"s_mov_b32 {sreg(S_THR)}, {hex(f32bits(THR))}")
     I(f"s_mov_b32 {sreg(S_NINF)}, 0xff800000")
     I(f"s_lshl_b32 {sreg(S_STEP)}, {sreg(S_LDK)}, 6")                       # bytes per 64-key tile
+    I(f"s_sub_u32 {sreg(S_MASKI)}, {sreg(S_NT)}, 1")
+    I(f"s_cmp_lt_u32 {sreg(S_LASTV)}, 64")
+    I(f"s_cselect_b32 {sreg(S_MASKI)}, {sreg(S_MASKI)}, -1")
     # buffer descriptors: base, stride 0, num_records, raw dword format (0x00020000 = the compiler's make_buffer_rsrc flags)
     for rs, base in ((S_KRS, S_K), (S_VRS, S_V)):
         I(f"s_mov_b32 {sreg(rs)}, {sreg(base)}")
@@ -377,6 +387,9 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
         I(f"v_lshlrev_b32 {vreg(t_x)}, 4, {vreg(t_x)}")
         I(f"v_mul_lo_u32 {vreg(V_DV + i)}, {vreg(t_key)}, {sreg(S_LDK)}")
         I(f"v_add_u32 {vreg(V_DV + i)}, {vreg(V_DV + i)}, {vreg(t_x)}")
+        if KNOB("M0_OFFS", 0) and i:
+            I(f"v_subrev_u32 {vreg(V_DK + i)}, {1024 * i}, {vreg(V_DK + i)}")
+            I(f"v_subrev_u32 {vreg(V_DV + i)}, {1024 * i}, {vreg(V_DV + i)}")
     # prologue staging: K(0..3), V(0..2)
     for t in range(4):
         for op in dma_pieces("K", t) + dma_step("K"):
@@ -581,22 +594,27 @@ def gen_tile(g: Gen, u: int):
     late = [op for t, op in fin if t >= 1000]        # row-sum adds deferred to phase B (ADD_LATE)
     fin = [(t, op) for t, op in fin if t < 1000]
     tmax = max([t for t, _ in fin] + [0])            # runs on into B_i, ahead of the P.V k-steps that consume it (k-step k starts at B gap 8 k)
-    placed = [(0.3 + span * t / (tmax + 1) + 0.001 * k, op) for k, (t, op) in enumerate(fin)]
+    placed = [(0.3 + (span - 0.3) * k / max(1, len(fin)), op) for k, (t, op) in enumerate(fin)]      # uniform by instruction index:
+                                                     # bursts of 3 exp + 5 VALU in one gap (placement by element) cost 3 % of the tile
     fillers = [(p_, op) for p_, op in placed if p_ < 32]
     fin_b = [(p_ - 32, op) for p_, op in placed if p_ >= 32] + spread(late, KNOB("LATE_LO", 1.3), KNOB("LATE_HI", 30.0))
-    for n in range(NVF):                              # the first ring-full of V(i-1) fragments, at the end of A_i
-        for k, op in enumerate(v_frag_reads(n, u - 1)):
-            fillers.append((32 - 2 * (NVF - n) + 0.9 + 0.05 * k, op))
+    vf_pos = []                                       # V(i-1) fragment n: read VF_LEAD gaps ahead of its first MFMA (B-phase index pv_index(n)),
+    lead = KNOB("VF_LEAD", 3.1)                      # never before the MFMAs of the fragment whose ring slot it takes over
+    for n in range(16):
+        pos = 32 + pv_index(n) - lead
+        if n >= NVF:
+            pos = max(pos, 32 + pv_index(n - NVF) + 1.9)
+        vf_pos.append(pos)
+        if pos < 32:
+            for k, op in enumerate(v_frag_reads(n, u - 1)):
+                fillers.append((pos + 0.05 * k, op))
     dma_a = KNOB("DMA_IN_A", 0)
     if dma_a and not KNOB("NO_DMA", 0):
         fillers += spread(dma_ops(u + 3, u + 2), 1.4, 30.5)
     g.phase(qk_mfmas(x), fillers)
     stamp(g, S_ACC)
     # ragged last tile: mask S(i) before its row max is taken
-    I(f"s_add_u32 {sreg(S_T0)}, {sreg(S_I)}, 1")
-    I(f"s_cmp_lg_u32 {sreg(S_T0)}, {sreg(S_NT)}")
-    I(f"s_cbranch_scc1 LL_MASK_RET_{u}")
-    I(f"s_cmp_ge_u32 {sreg(S_LASTV)}, 64")
+    I(f"s_cmp_lg_u32 {sreg(S_I)}, {sreg(S_MASKI)}")                          # S_MASKI = nt - 1 if the last tile is ragged, else -1
     I(f"s_cbranch_scc1 LL_MASK_RET_{u}")
     I(f"s_mov_b32 {sreg(S_RET)}, {mask_rets(x).index(f'LL_MASK_RET_{u}')}")
     I(f"s_branch LL_MASK_{x}")
@@ -605,12 +623,13 @@ def gen_tile(g: Gen, u: int):
     fillers = []
     for k, op in enumerate([] if KNOB("NO_KREAD", 0) else k_frag_reads(u + 1)):
         fillers.append((0.5 + k * KNOB("KREAD_STEP", 0.95), op))
-    for n in range(NVF, 16):                          # fragment n re-uses the ring slot of fragment n - NVF: read it right after that one's MFMAs
-        for k, op in enumerate(v_frag_reads(n, u - 1)):
-            fillers.append((pv_index(n - NVF) + 1.9 + 0.02 * k, op))
-    fillers += spread(start_ops(x)[(-3 if KNOB("NO_START", 0) else 0):], 3.2, KNOB("START_END", 27.0))
+    for n in range(16):
+        if vf_pos[n] >= 32:
+            for k, op in enumerate(v_frag_reads(n, u - 1)):
+                fillers.append((vf_pos[n] - 32 + 0.02 * k, op))
+    fillers += spread(start_ops(x)[(-3 if KNOB("NO_START", 0) else 0):], 3.2, KNOB("START_END", 27.0 if LSUM else 22.0))
     if not dma_a and not KNOB("NO_DMA", 0):
-        fillers += spread(dma_ops(u + 3, u + 2), 20.4, 39.5)
+        fillers += spread(dma_ops(u + 3, u + 2), 20.4 if LSUM else 16.4, 39.5 if LSUM else 31.5)
     fillers += fin_b
     g.phase(pv_mfmas(y), fillers)
     # rescale decision (after every P.V of tile i-1 has issued), then the tile barrier

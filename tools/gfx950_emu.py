@@ -787,7 +787,7 @@ class Machine:
     def _lds_dma(self, w, i, addrs, valid):
         """16 bytes per lane -> LDS at M0[15:0]?? (full M0 used) + instruction offset + 16 * lane"""
         self.full_exec(w, "LDS-DMA")
-        base = int(w.s[124])
+        base = int(w.s[124]) + int(i.mods.get("offset", 0))      # the instruction offset moves the LDS destination too (as the source)
         if base + 1024 > self.lds.size:
             raise EmuError(f"LDS-DMA destination {base:#x} out of range")
 
