@@ -697,6 +697,7 @@ static int g_gemm_lds_epi = 1;
 static int g_gemm_ws_mask = 15;     // which launches gemm_ws applies to: 1 = 256x128 with K >= 4096 (FFN2), 2 = 256x128 otherwise, 4 = 256x192, 8 = 256x224
 static int g_gemm_ws = 0;            // wave-specialised staging (gemm_kernel_ws): 0 off, 1 / 2 loader waves, for variants 2, 5, 6
 static int g_gemm_stagger = 0;       // 1: 256x128 tiling with waves 4-7 half a K-step behind (gemm_kernel_v2<.., true>)
+static int g_gemm_asm = 0;
 static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
@@ -730,6 +731,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "conv_halo")) { ll_set_conv_halo_internal(value); return LL_OK; }
   if (!strcmp(key, "gemm_splitk_l2")) { ll_set_splitk_l2_internal(value); return LL_OK; }
   if (!strcmp(key, "gemm_splitk_fault")) { ll_set_splitk_fault_internal(value); return LL_OK; }
+  if (!strcmp(key, "gemm_asm")) { g_gemm_asm = value; return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }
@@ -852,9 +854,19 @@ extern "C" int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap) {
 }
 
 // ===============================================================================================================
+// tuning key gemm_asm (declared near ll_set_tuning): bit 0 = bf16 block linears on the generated one-wave-per-SIMD kernels (gemm_asm.hip) where a
+                                // tile width fits (FFN1: 256 x 224 + GELU; N <= 2048: 256 x 128 with bias / gate-residual / residual);
+                                // bit 1 = ll_gemm_bf16_splitk calls (FFN2) take them too instead of the split-K kernel
+int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
+                    int gm, hipStream_t s);
+const char* gemm_asm_plan(int M, int N, int K, int epilogue, char* out, int cap);
+
 template <bool I8>
 static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, int K, size_t xrow_bytes, size_t wrow_bytes,
                        int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
+  if (!I8 && (g_gemm_asm & 1) && wrow_bytes == (size_t)K * 2 &&
+      gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s))
+    return 0;
   const int kbytes = I8 ? K : 2 * K;
   const int nk = kbytes / ROWB;
   const int variant = pick_gemm_variant(M, N);
@@ -1064,7 +1076,7 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
                          size_t wrow_bytes, int ldo, int epilogue, const EpiArgs& ea, void* workspace, long long workspace_bytes,
                          hipStream_t s) {
   const int kbytes = I8 ? K : 2 * K;
-  if (!splitk_eligible(M, N, kbytes) || workspace == nullptr) {
+  if (!splitk_eligible(M, N, kbytes) || workspace == nullptr || (!I8 && (g_gemm_asm & 2))) {
     launch_gemm<I8>(x, w, out, M, N, K, xrow_bytes, wrow_bytes, ldo, epilogue, ea, s);
     return ll_check_launch(fn);
   }

@@ -1,0 +1,71 @@
+// Hand-scheduled bf16 GEMMs for the block linears on gfx950: 4 waves per 256 x WN output tile, one wave per SIMD, accumulators in
+// AGPRs, generated body (gen/gemm_asm_gen.py -> build/gemm_asm_<WN>_<EPI>.inc; structure, pipeline and CPU checks are described
+// there).  This file computes each workgroup's tile and scalar arguments, pins them to the registers the text expects and launches.
+// Replaces gemm_kernel_v5 / v2 for the shapes ll_gemm_bf16 routes here (tuning key gemm_asm); rounding points as gemm_common.h.
+#include "gemm_common.h"
+
+#define GA_NAME gemm_asm_224_gelu
+#define GA_WN 224
+#define GA_INC "build/gemm_asm_224_1.inc"
+#include "gemm_asm_kernel.inl"
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asm_128_bias
+#define GA_WN 128
+#define GA_INC "build/gemm_asm_128_0.inc"
+#include "gemm_asm_kernel.inl"
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asm_128_gate_res
+#define GA_WN 128
+#define GA_INC "build/gemm_asm_128_2.inc"
+#include "gemm_asm_kernel.inl"
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asm_128_res
+#define GA_WN 128
+#define GA_INC "build/gemm_asm_128_3.inc"
+#include "gemm_asm_kernel.inl"
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+
+// 1 = launched; 0 = shape / epilogue not covered here (the caller takes the HIP kernels)
+int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
+                    int gm, hipStream_t s) {
+  if (ea.v_out != nullptr || ea.sx != nullptr || M <= 0 || K % 32 != 0 || K < 128 || (ldx % 8) != 0) return 0;
+  if (epilogue == LL_EPI_BIAS_GATE_RES && (ea.mod != nullptr || ea.frame_len <= 0)) return 0;
+  if ((long long)256 * ldx * 2 >= 0x7fffffffLL || (long long)256 * K * 2 >= 0x7fffffffLL) return 0;
+  const void* fn = nullptr;
+  int wn = 0;
+  if (epilogue == LL_EPI_BIAS_GELU && N % 224 == 0) { fn = (const void*)gemm_asm_224_gelu; wn = 224; }
+  else if (N % 128 == 0 && N <= 2048) {
+    wn = 128;
+    fn = epilogue == LL_EPI_BIAS ? (const void*)gemm_asm_128_bias
+         : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asm_128_gate_res
+         : epilogue == LL_EPI_BIAS_RES ? (const void*)gemm_asm_128_res : nullptr;
+  }
+  if (!fn) return 0;
+  static bool attr[4] = {false, false, false, false};
+  const int slot = fn == (const void*)gemm_asm_224_gelu ? 0 : fn == (const void*)gemm_asm_128_bias ? 1 : fn == (const void*)gemm_asm_128_gate_res ? 2 : 3;
+  if (!attr[slot]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr[slot] = true; }
+  const int ntm = (M + 255) / 256, ntn = N / wn;
+  const bf16* gate = epilogue == LL_EPI_BIAS_GATE_RES ? ea.e + (size_t)ea.gate_idx * N : nullptr;
+  const int gstride = ea.nmod * N * 2;
+  void* args[] = {(void*)&x, (void*)&w, (void*)&ea.bias, (void*)&out, (void*)&ea.res, (void*)&gate, (void*)&M, (void*)&N, (void*)&K,
+                  (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm};
+  (void)hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, 128 * 1024, s);
+  return 1;
+}
+
+const char* gemm_asm_plan(int M, int N, int K, int epilogue, char* out, int cap) {
+  const bool gelu = epilogue == LL_EPI_BIAS_GELU && N % 224 == 0;
+  const int wn = gelu ? 224 : 128;
+  snprintf(out, (size_t)cap, "gemm_asm_%d (4 waves x 64 rows, one wave per SIMD, generated schedule) tile 256x%d, %d workgroups", wn, wn,
+           ((M + 255) / 256) * (N / wn));
+  (void)K;
+  return out;
+}

@@ -1,0 +1,25 @@
+// included by gemm_asm.hip once per (tile width, epilogue) with GA_NAME / GA_WN / GA_INC defined
+__global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, const bf16* __restrict__ W,
+                                                  const bf16* __restrict__ bias, bf16* __restrict__ Y,
+                                                  const bf16* __restrict__ res, const bf16* __restrict__ gate, int M, int N,
+                                                  int K, int ldx, int ldo, int frame_len, int gate_stride, int ntm, int ntn,
+                                                  int gm) {
+  int mt, nt;
+  tile_of(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, gm, mt, nt);
+  const int m0 = mt * 256, n0 = nt * (GA_WN);
+  unsigned long long xb = (unsigned long long)(X + (size_t)m0 * ldx), wb = (unsigned long long)(W + (size_t)n0 * K);
+  unsigned long long yb = (unsigned long long)(Y + (size_t)m0 * ldo + n0), bb = (unsigned long long)(bias + n0);
+  unsigned long long rb = (unsigned long long)(res ? res + (size_t)m0 * ldo + n0 : Y), gb = (unsigned long long)(gate ? gate + n0 : bias);
+  unsigned ldx_b = (unsigned)ldx * 2u, ldw_b = (unsigned)K * 2u, ldo_b = (unsigned)ldo * 2u;
+  unsigned rows = (unsigned)(M - m0), cols = (unsigned)(N - n0), nk = (unsigned)(K / 32);
+  unsigned flen = (unsigned)(frame_len > 0 ? frame_len : 1), gstride = (unsigned)gate_stride, um0 = (unsigned)m0;
+  unsigned tid = threadIdx.x;
+  asm volatile(
+#include GA_INC
+      :
+      : "{s[8:9]}"(xb), "{s[10:11]}"(wb), "{s[12:13]}"(yb), "{s[14:15]}"(bb), "{s[16:17]}"(rb), "{s[18:19]}"(gb),
+        "{s20}"(ldx_b), "{s21}"(ldw_b), "{s22}"(ldo_b), "{s23}"(rows), "{s24}"(cols), "{s25}"(nk), "{s26}"(flen),
+        "{s27}"(gstride), "{s28}"(um0), "{v0}"(tid)
+      : "memory", "v255", "a255", "s63", "vcc");
+  __builtin_unreachable();
+}

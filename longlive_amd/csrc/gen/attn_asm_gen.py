@@ -778,6 +778,7 @@ def lint(text):
          VALU write of a VGPR -> MFMA reads it as A / B / C: >= 2
          VALU write -> v_permlane*_swap reads it: >= 2
          SALU write of m0 -> LDS-DMA: >= 1
+         transcendental (v_exp / v_rcp / ...) result -> read by the next VALU / MFMA instruction: >= 1
     Straight-line approximation: branches and labels reset nothing (distances only grow across them on the paths taken here)."""
     problems = []
     hist = []                                         # (states_since, kind, regs)
@@ -817,6 +818,9 @@ def lint(text):
                     problems.append(f"{ln}: `{line}` reads VALU result of `{src}` after {dist} states")
                 if mn.startswith("v_permlane") and (regs & reads) and dist < 2:
                     problems.append(f"{ln}: `{line}` swaps VALU result of `{src}` after {dist} states")
+            elif kind == "trans_w":
+                if (is_valu or is_mfma) and (regs & reads) and dist < 1:
+                    problems.append(f"{ln}: `{line}` reads the transcendental result of `{src}` in the next instruction (1 wait state needed)")
             elif kind == "m0_w":
                 if "lds" in line and mn.startswith("buffer_load") and dist < 1:
                     problems.append(f"{ln}: `{line}` right after m0 write")
@@ -825,6 +829,8 @@ def lint(text):
             hist.append((0, "mfma_d", regs_of(ops[0]), line))
         elif is_valu and writes:
             hist.append((0, "valu_w", writes, line))
+            if mn.split("_e")[0] in ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32"):
+                hist.append((0, "trans_w", writes, line))     # gfx940+: trans result -> VALU use needs 1 wait state (hipcc pads s_nop 0)
         if mn.startswith("s_") and ops and ops[0] == "m0":
             hist.append((0, "m0_w", set(), line))
     return problems

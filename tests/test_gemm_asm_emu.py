@@ -1,0 +1,102 @@
+"""The generated GEMM kernels (longlive_amd/csrc/gen/gemm_asm_gen.py) executed on the CPU by tools/gfx950_emu.py: one workgroup
+(a 256 x WN tile with a ragged M edge, idle waves included) for every epilogue, against a numpy restatement of gemm_common.h's
+rounding points; both completion models of the emulator; lint clean; assembles for gfx950."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "longlive_amd", "csrc", "gen"))
+
+import gemm_asm_gen as G          # noqa: E402
+import gfx950_emu as E            # noqa: E402
+
+
+def bf(x):
+    return E.bf16_round(np.asarray(x, dtype=np.float32)).astype(np.uint16)
+
+
+def f32(bits):
+    return E.bf16_to_f32(np.asarray(bits, dtype=np.uint32))
+
+
+def rbf(x):
+    return f32(bf(x))
+
+
+def run_case(WN, epi, mode, rows_valid=200, K=160, seed=0, m0=300, frame_len=130):
+    rng = np.random.default_rng(seed)
+    text = G.generate(WN, epi, f"T{WN}E{epi}")
+    assert G.lint(text) == []
+    N = WN
+    x = bf(rng.standard_normal((rows_valid, K)))
+    w = bf(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = bf(0.1 * rng.standard_normal(N))
+    res = bf(rng.standard_normal((rows_valid, N)))
+    nframes = (m0 + rows_valid + frame_len - 1) // frame_len + 1
+    gate = bf(0.5 * rng.standard_normal((nframes, N)))
+    mem = E.Memory()
+    ax, aw, ab, ar, ag = mem.alloc(x), mem.alloc(w), mem.alloc(bias), mem.alloc(res), mem.alloc(gate)
+    ay = mem.alloc(np.full((rows_valid, N), 0x7FC0, dtype=np.uint16))
+    m = E.Machine(text, mem, 4, mode=mode, lds_bytes=128 * 1024)
+    for wv in m.waves:
+        s = wv.s
+        def put64(i, val):
+            s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
+        put64(G.S_X, ax); put64(G.S_W, aw); put64(G.S_Y, ay); put64(G.S_BIAS, ab); put64(G.S_RES, ar); put64(G.S_GATE, ag)
+        s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K * 2, K * 2, N * 2
+        s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 32
+        s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
+        wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
+        wv.v[1:] = 0x7FC0BEEF
+        wv.a[:] = 0x7FC0BEEF
+    m.run()
+    got = f32(mem.get(ay).view(np.uint16).reshape(rows_valid, N)).astype(np.float64)
+    acc = (f32(x).astype(np.float64) @ f32(w).astype(np.float64).T).astype(np.float32)
+    v = rbf(acc + f32(bias)[None, :])
+    if epi == G.EPI_BIAS:
+        want = v
+    elif epi == G.EPI_GELU:
+        xx = v.astype(np.float32)
+        k0, k1, ce = np.float32(0.7978845608028654), np.float32(0.044715), np.float32(-2.0 * 1.4426950408889634)
+        u = k0 * (xx + ((k1 * xx) * xx) * xx)
+        e = np.exp2((ce * u).astype(np.float64)).astype(np.float32)
+        want = rbf(xx * (np.float32(1.0) / (np.float32(1.0) + e)))
+    elif epi == G.EPI_RES:
+        want = rbf(f32(res) + v)
+    else:
+        frames = (m0 + np.arange(rows_valid)) // frame_len
+        gt = f32(gate)[frames]
+        want = rbf(f32(res) + rbf(v * gt))
+    return got, want.astype(np.float64)
+
+
+@pytest.mark.parametrize("epi", [G.EPI_BIAS, G.EPI_GELU, G.EPI_GATE_RES, G.EPI_RES])
+def test_gemm_asm_epilogues(epi):
+    got, want = run_case(224, epi, "lazy")
+    assert np.isfinite(got).all()
+    # one bf16 ulp of the fp32 accumulation-order difference at most, almost all elements identical
+    ulp = np.maximum(np.abs(want), 2.0 ** -6) * 2.0 ** -7
+    assert (np.abs(got - want) <= (1.01 if epi == G.EPI_BIAS else 2.02) * ulp + (0 if epi in (G.EPI_BIAS, G.EPI_GELU) else 4e-2)).all(), np.abs(got - want).max()
+    assert (got == want).mean() > 0.97, (got == want).mean()
+
+
+def test_gemm_asm_eager_model_and_small_tile():
+    got, want = run_case(128, G.EPI_BIAS, "eager", rows_valid=70, K=96)
+    assert (got == want).mean() > 0.97 and np.abs(got - want).max() < 0.05
+
+
+def test_gemm_asm_text_assembles(tmp_path):
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm assembler here")
+    for epi in (G.EPI_BIAS, G.EPI_GELU, G.EPI_GATE_RES, G.EPI_RES):
+        src = tmp_path / f"k{epi}.s"
+        src.write_text('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n.text\nkernel:\n' + G.generate(224, epi, f"A{epi}"))
+        r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "k.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[:2000]

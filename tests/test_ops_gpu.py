@@ -526,6 +526,42 @@ def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
         assert torch.equal(first, want)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4680, 8960, 1536, "gelu"), (4680, 1536, 1536, "gate"), (4680, 1536, 1536, "res"),
+                                       (4680, 1536, 1536, "bias"), (4680, 1536, 8960, "gate"), (300, 224, 128, "gelu"),
+                                       (70, 128, 192, "bias"), (9360, 1536, 1536, "gate"), (513, 448, 192, "gelu")])
+def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
+    """The generated one-wave-per-SIMD GEMM kernels (tuning key gemm_asm; gen/gemm_asm_gen.py) against the HIP kernels they replace,
+    at the block linears' shapes (FFN1, O / cross-o / cross-q, FFN2, B = 2) and at ragged edges: same products, the fp32 sum taken in
+    another order -> <= 1-2 bf16 ulp apart (absolute bound where a residual cancels), and against fp64."""
+    x = hn("gx", (M, K)).to(DEV)
+    w = (hn("gw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("gb", (N,), 0.1).to(DEV)
+    kw = {}
+    code = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "gate": ops.EPI_BIAS_GATE_RES, "res": ops.EPI_BIAS_RES}[epi]
+    if epi in ("gate", "res"):
+        kw["res"] = hn("gr", (M, N)).to(DEV)
+    if epi == "gate":
+        F_ = 3 if M % 3 == 0 else 1
+        kw.update(e=hn("ge", (1, F_, 6, N), 0.5).to(DEV), mod=None, gate_idx=5, rows_per_batch=M, frame_len=M // F_)
+    want = ops.gemm(x, w, b, code, **kw)
+    try:
+        _set_tuning("gemm_asm", 1)
+        from longlive_amd import _lib
+        import ctypes as C
+        buf = C.create_string_buffer(256)
+        got = ops.gemm(x, w, b, code, **kw)
+        again = ops.gemm(x, w, b, code, **kw)
+    finally:
+        _set_tuning("gemm_asm", 0)
+    assert torch.equal(got, again)
+    fused = epi in ("gate", "res")
+    assert_bf16_close(got, want, 2, 0.97, f"gemm_asm {M}x{N}x{K} {epi}", atol=4e-2 if fused else None)
+    if M * N * K < 2e9:
+        ref = (x.double() @ w.double().t() + b.double()).cpu()
+        if epi == "bias":
+            assert rel_l2(got.cpu(), ref) < 4e-3
+
+
 def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
     """The partial tiles live at fixed workspace addresses: alternate two different activations so that a partner reading the
     PREVIOUS launch's bytes (a stale line somewhere between the two workgroups) cannot reproduce the right answer."""

@@ -533,6 +533,24 @@ class Machine:
     def i_v_cvt_pk_bf16_f32(self, w, i):
         self._valu(w, i, lambda a, b: bf16_round(u2f(a)) | (bf16_round(u2f(b)) << 16), 2)
 
+    def i_v_cvt_u32_f32(self, w, i):
+        def f(a):
+            x = np.nan_to_num(u2f(a).astype(np.float64), nan=0.0)
+            return np.clip(np.trunc(x), 0, 4294967295).astype(np.uint32)
+        self._valu(w, i, f, 1)
+
+    def _pk(self, w, i, f):
+        d, a, b = i.ops
+        def part(op, k):
+            return u2f(self.rv(w, Op(op.kind, op.idx + k, 1, op.val)) if op.kind != "imm" else self.rv(w, op))
+        with np.errstate(all="ignore"):
+            lo, hi = f(part(a, 0), part(b, 0)), f(part(a, 1), part(b, 1))
+        self.wv(w, d, f2u(lo.astype(np.float32)), 0)
+        self.wv(w, d, f2u(hi.astype(np.float32)), 1)
+
+    def i_v_pk_mul_f32(self, w, i): self._pk(w, i, lambda a, b: a * b)
+    def i_v_pk_add_f32(self, w, i): self._pk(w, i, lambda a, b: a + b)
+
     def i_v_cvt_f32_u32(self, w, i): self._valu(w, i, lambda a: f2u(a.astype(np.float32)), 1)
     def i_v_cvt_f32_i32(self, w, i): self._valu(w, i, lambda a: f2u(a.view(np.int32).astype(np.float32)), 1)
 
@@ -573,6 +591,8 @@ class Machine:
     def i_v_cmp_gt_u32(self, w, i): self._cmp(w, i, lambda a, b: a > b, "u")
     def i_v_cmp_lt_u32(self, w, i): self._cmp(w, i, lambda a, b: a < b, "u")
     def i_v_cmp_ge_u32(self, w, i): self._cmp(w, i, lambda a, b: a >= b, "u")
+    def i_v_cmp_le_u32(self, w, i): self._cmp(w, i, lambda a, b: a <= b, "u")
+
     def i_v_cmp_eq_u32(self, w, i): self._cmp(w, i, lambda a, b: a == b, "u")
     def i_v_cmp_ne_u32(self, w, i): self._cmp(w, i, lambda a, b: a != b, "u")
 

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <functional>
+#include <string>
 #include <vector>
 
 #include "longlive_hip.h"
@@ -91,7 +92,7 @@ static void bench_gemm(const char* name, int M, int N, int K, int epi, int iters
   Buf res((size_t)M * N, 1.0f), e((size_t)3 * 6 * N, 0.5f), mod((size_t)6 * N, 0.1f);
   hipStream_t s = 0;
   auto fn = [&]() {
-    LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, M, N, K, K, N, epi, res.d, e.d, mod.d, 6, 2, M, M / 3, s));
+    LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, M, N, K, K, N, epi, res.d, e.d, getenv("KBENCH_MOD") ? mod.d : nullptr, 6, 2, M, M / 3, s));   // as shipped: e is the modulation table (mod = NULL)
   };
   double ms = time_ms(s, iters, fn);
   // spot check (epilogue 0 and 1 only: plain value check)
@@ -335,6 +336,18 @@ static void bench_layerseq(int layers) {
 }
 
 int main(int argc, char** argv) {
+  if (const char* tun = getenv("LL_TUNING")) {      // LL_TUNING=key=value,...: the kernel A/B switches bench.py accepts
+    std::string t(tun);
+    size_t pos = 0;
+    while (pos < t.size()) {
+      size_t c = t.find(',', pos);
+      std::string kv = t.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+      size_t eq = kv.find('=');
+      if (eq != std::string::npos) LL(ll_set_tuning(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)));
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+  }
   const char* what = argc > 1 ? argv[1] : "all";
   int iters = argc > 2 ? atoi(argv[2]) : 20;
   bool all = !strcmp(what, "all");
