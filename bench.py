@@ -354,11 +354,9 @@ def kernel_table(summary, quant, splitk=False):
     for tag, s in sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"]):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
-            name = _plan_text(lib.ll_gemm_plan, *gemm_shapes[tag], i8)
-            if tag == "gemm_f2" and splitk and not i8 and lib.ll_gemm_splitk_plan(*gemm_shapes[tag], i8) == 1:   # int8: _lin drops split-K
-                M_, N_, _ = gemm_shapes[tag]
-                name = (f"gemm_kernel_v4sk<{'i8' if i8 else 'bf16'}> tile 256x256 x split-K 2, {2 * ((M_ + 255) // 256) * (N_ // 256)} workgroups, "
-                        "halves reduced in the epilogue")
+            epi = {"gemm_qkv": 0, "gemm_o": 2, "gemm_cq": 0, "gemm_co": 3, "gemm_f1": 1, "gemm_f2": 2}[tag]      # LL_EPI_* of the call
+            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, 0 if tag == "gemm_qkv" else 1,
+                              1 if (tag == "gemm_f2" and splitk and not i8) else 0)                              # int8: _lin drops split-K
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)
         elif tag == "flash_attn_cross":

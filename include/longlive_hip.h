@@ -47,11 +47,22 @@ const char* ll_last_error(void);
  * 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;  "attn_variant" 0 = simple, 1 = software-pipelined, 2 = + ping-pong wave
  * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on;  "attn_sk_wgs" -1 = stream-K attention off
  * (default: measured slower at the power limit), 0 = on when it shortens the walk, N = force N workgroups;  "gemm_group_m" = m-tiles per group of the GEMM tile walk
- * (default 4; <= 1: N fastest).  Unknown key: LL_ERR_INVALID_ARG. */
+ * (default 4; <= 1: N fastest);  "attn_asm" 1 (default) = the generated one-wave-per-SIMD self-attention kernel
+ * (flash_attn_asm_kernel) for >= 1024 keys, 0 = the HIP ping-pong kernel;  "gemm_asm" bit 0 = the generated GEMM kernels
+ * (gemm_asm_224_gelu: FFN1; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual) where they cover the call,
+ * bit 1 = also in place of the split-K kernel, bits 2 / 3 = leave the GELU / the 128-wide kernels out (default 3; 0 = HIP
+ * kernels only);  "attn_mfma16" 1 = 16x16x32 MFMA variant of the HIP attention kernel (measured slower; A/B only);
+ * "gemm_splitk_fault" 1 = test hook: the split-K partner never signals (exercises the bounded wait).
+ * Unknown key: LL_ERR_INVALID_ARG. */
 int ll_set_tuning(const char* key, int value);
 /* Host-only introspection: the kernel instance + tile + grid that ll_gemm_bf16 / ll_gemm_w8a8 / ll_flash_attn would launch
  * for a shape under the current tuning, as text in out[cap] (bench.py's per-kernel table names kernels from here). */
 int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap);
+/* The same for a call whose epilogue is known (LL_EPI_*): names the generated one-wave-per-SIMD kernel (gemm_asm_*, tuning key
+ * "gemm_asm") where ll_gemm_bf16 (splitk_call = 0) or ll_gemm_bf16_splitk with a workspace (splitk_call = 1) takes it, the
+ * split-K kernel where that one runs, else ll_gemm_plan's text.  plain = 1: no V-cache output and no per-batch modulation
+ * vector (every block linear of the pipeline except QKV). */
+int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int plain, int splitk_call, char* out, int cap);
 int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, int have_workspace, char* out,
                        int cap);
 

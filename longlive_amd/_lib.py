@@ -19,6 +19,7 @@ SIGNATURES = {
     "ll_last_error": [],
     "ll_set_tuning": [C.c_char_p, _i],
     "ll_gemm_plan": [_i, _i, _i, _i, C.c_char_p, _i],
+    "ll_gemm_plan_epi": [_i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
     "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
     "ll_flash_attn_workspace_bytes": [],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],

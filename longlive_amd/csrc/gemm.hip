@@ -697,7 +697,7 @@ static int g_gemm_lds_epi = 1;
 static int g_gemm_ws_mask = 15;     // which launches gemm_ws applies to: 1 = 256x128 with K >= 4096 (FFN2), 2 = 256x128 otherwise, 4 = 256x192, 8 = 256x224
 static int g_gemm_ws = 0;            // wave-specialised staging (gemm_kernel_ws): 0 off, 1 / 2 loader waves, for variants 2, 5, 6
 static int g_gemm_stagger = 0;       // 1: 256x128 tiling with waves 4-7 half a K-step behind (gemm_kernel_v2<.., true>)
-static int g_gemm_asm = 0;
+static int g_gemm_asm = 3;         // generated kernels where they cover the call, also in place of split-K (see launch_gemm)
 static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
@@ -853,18 +853,29 @@ extern "C" int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap) {
   return LL_OK;
 }
 
+// ll_gemm_plan for a call whose epilogue is known: names the generated kernel where ll_gemm_bf16 (splitk_call = 0) or
+// ll_gemm_bf16_splitk (splitk_call = 1, workspace given) would take it under the current tuning; `plain` = 1 when the call has no
+// V-cache output and no per-batch modulation vector (the block linears of the pipeline except QKV).
+extern "C" int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int plain, int splitk_call, char* out, int cap);
+
 // ===============================================================================================================
 // tuning key gemm_asm (declared near ll_set_tuning): bit 0 = bf16 block linears on the generated one-wave-per-SIMD kernels (gemm_asm.hip) where a
                                 // tile width fits (FFN1: 256 x 224 + GELU; N <= 2048: 256 x 128 with bias / gate-residual / residual);
                                 // bit 1 = ll_gemm_bf16_splitk calls (FFN2) take them too instead of the split-K kernel
 int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
                     int gm, hipStream_t s);
-const char* gemm_asm_plan(int M, int N, int K, int epilogue, char* out, int cap);
+int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain_epilogue, int frame_len);
+const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap);
+static bool gemm_asm_wanted(int epilogue) {
+  return (g_gemm_asm & 1) && !((g_gemm_asm & 4) && epilogue == LL_EPI_BIAS_GELU) && !((g_gemm_asm & 8) && epilogue != LL_EPI_BIAS_GELU);
+}
 
 template <bool I8>
 static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, int K, size_t xrow_bytes, size_t wrow_bytes,
                        int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
-  if (!I8 && (g_gemm_asm & 1) && wrow_bytes == (size_t)K * 2 &&
+  // gemm_asm: bit 0 = generated kernels for the shapes they cover, bit 1 = also instead of split-K; bit 2 / bit 3 leave the
+  // GELU (256 x 224) / the 128-wide kernels out (A/B of their share in the pipeline's power budget)
+  if (!I8 && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2 &&
       gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s))
     return 0;
   const int kbytes = I8 ? K : 2 * K;
@@ -1053,6 +1064,21 @@ extern "C" long long ll_gemm_splitk_workspace_bytes(int M, int N) {
 }
 extern "C" int ll_gemm_splitk_plan(int M, int N, int K, int int8) { return splitk_eligible(M, N, int8 ? K : 2 * K) ? 1 : 0; }
 
+extern "C" int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int plain, int splitk_call, char* out, int cap) {
+  LL_REQUIRE(out != nullptr && cap > 0, "ll_gemm_plan_epi: needs an output buffer");
+  const bool sk = splitk_call && splitk_eligible(M, N, int8 ? K : 2 * K);
+  if (!int8 && gemm_asm_wanted(epilogue) && (!sk || (g_gemm_asm & 2))) {
+    const int wn = gemm_asm_width(M, N, K, K, epilogue, plain != 0, 1);
+    if (wn) { gemm_asm_plan(M, N, wn, epilogue, out, cap); return LL_OK; }
+  }
+  if (sk) {
+    snprintf(out, (size_t)cap, "gemm_kernel_v4sk<%s> tile 256x256 x split-K 2, %d workgroups, halves reduced in the epilogue",
+             int8 ? "i8" : "bf16", 2 * ((M + 255) / 256) * (N / 256));
+    return LL_OK;
+  }
+  return ll_gemm_plan(M, N, K, int8, out, cap);
+}
+
 // Reads back the workspace's error word (BLOCKING: synchronises `stream`).  *status = 0: every hand-off of every launch on this
 // workspace so far completed; otherwise the epoch of a launch whose partner workgroup did not arrive within the poll budget --
 // that launch's output is invalid.  The word is cleared, so the workspace can be used again.
@@ -1076,10 +1102,15 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
                          size_t wrow_bytes, int ldo, int epilogue, const EpiArgs& ea, void* workspace, long long workspace_bytes,
                          hipStream_t s) {
   const int kbytes = I8 ? K : 2 * K;
-  if (!splitk_eligible(M, N, kbytes) || workspace == nullptr || (!I8 && (g_gemm_asm & 2))) {
+  if (!splitk_eligible(M, N, kbytes) || workspace == nullptr) {
     launch_gemm<I8>(x, w, out, M, N, K, xrow_bytes, wrow_bytes, ldo, epilogue, ea, s);
     return ll_check_launch(fn);
   }
+  // gemm_asm bit 1: the generated 256 x 128 kernel where it covers the call (measured: 109 us / 145 mJ against 123 us / 166 mJ
+  // for the split-K kernel at FFN2's shape, profiles/r03_kenergy_gemm.txt) -- no partner hand-off on that path
+  if (!I8 && (g_gemm_asm & 2) && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2 &&
+      gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s))
+    return ll_check_launch(fn);
   LL_REQUIRE(workspace_bytes >= ll_gemm_splitk_workspace_bytes(M, N) && ((size_t)workspace & 15) == 0,
              "%s: workspace of %lld bytes, need %lld (16-byte aligned)", fn, workspace_bytes, ll_gemm_splitk_workspace_bytes(M, N));
   const int tiles = splitk_tiles(M, N), ntn = N / 256, nkh = kbytes / (2 * ROWB);

@@ -33,39 +33,40 @@
 #undef GA_WN
 #undef GA_INC
 
+// tile width of the generated kernel that covers this call, 0 = none (the caller takes the HIP kernels)
+int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain_epilogue, int frame_len) {
+  if (!plain_epilogue || M <= 0 || K % 64 != 0 || K < 256 || (ldx % 8) != 0) return 0;      // plain = no V-cache output, no int8 scales, no modulation vector
+  if (epilogue == LL_EPI_BIAS_GATE_RES && frame_len <= 0) return 0;
+  if ((long long)256 * ldx * 2 >= 0x7fffffffLL || (long long)256 * K * 2 >= 0x7fffffffLL) return 0;
+  if (epilogue == LL_EPI_BIAS_GELU) return N % 224 == 0 ? 224 : 0;
+  if (N % 128 == 0 && N <= 2048 && (epilogue == LL_EPI_BIAS || epilogue == LL_EPI_BIAS_GATE_RES || epilogue == LL_EPI_BIAS_RES)) return 128;
+  return 0;
+}
+
 // 1 = launched; 0 = shape / epilogue not covered here (the caller takes the HIP kernels)
 int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
                     int gm, hipStream_t s) {
-  if (ea.v_out != nullptr || ea.sx != nullptr || M <= 0 || K % 32 != 0 || K < 128 || (ldx % 8) != 0) return 0;
-  if (epilogue == LL_EPI_BIAS_GATE_RES && (ea.mod != nullptr || ea.frame_len <= 0)) return 0;
-  if ((long long)256 * ldx * 2 >= 0x7fffffffLL || (long long)256 * K * 2 >= 0x7fffffffLL) return 0;
-  const void* fn = nullptr;
-  int wn = 0;
-  if (epilogue == LL_EPI_BIAS_GELU && N % 224 == 0) { fn = (const void*)gemm_asm_224_gelu; wn = 224; }
-  else if (N % 128 == 0 && N <= 2048) {
-    wn = 128;
-    fn = epilogue == LL_EPI_BIAS ? (const void*)gemm_asm_128_bias
-         : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asm_128_gate_res
-         : epilogue == LL_EPI_BIAS_RES ? (const void*)gemm_asm_128_res : nullptr;
-  }
-  if (!fn) return 0;
+  const int wn = gemm_asm_width(M, N, K, ldx, epilogue, ea.v_out == nullptr && ea.sx == nullptr && ea.mod == nullptr, ea.frame_len);
+  if (!wn) return 0;
+  const void* fn = wn == 224 ? (const void*)gemm_asm_224_gelu
+                   : epilogue == LL_EPI_BIAS ? (const void*)gemm_asm_128_bias
+                   : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asm_128_gate_res : (const void*)gemm_asm_128_res;
   static bool attr[4] = {false, false, false, false};
   const int slot = fn == (const void*)gemm_asm_224_gelu ? 0 : fn == (const void*)gemm_asm_128_bias ? 1 : fn == (const void*)gemm_asm_128_gate_res ? 2 : 3;
-  if (!attr[slot]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr[slot] = true; }
+  const int lds = 3 * wn * 128 + 4 * 2 * 8192;      // gen/gemm_asm_gen.py Cfg.lds_bytes: 3 W slots of WN rows x 128 B + 2 X units of 8 KiB per wave
+  if (!attr[slot]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr[slot] = true; }
   const int ntm = (M + 255) / 256, ntn = N / wn;
   const bf16* gate = epilogue == LL_EPI_BIAS_GATE_RES ? ea.e + (size_t)ea.gate_idx * N : nullptr;
   const int gstride = ea.nmod * N * 2;
   void* args[] = {(void*)&x, (void*)&w, (void*)&ea.bias, (void*)&out, (void*)&ea.res, (void*)&gate, (void*)&M, (void*)&N, (void*)&K,
                   (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm};
-  (void)hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, 128 * 1024, s);
+  (void)hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s);
   return 1;
 }
 
-const char* gemm_asm_plan(int M, int N, int K, int epilogue, char* out, int cap) {
-  const bool gelu = epilogue == LL_EPI_BIAS_GELU && N % 224 == 0;
-  const int wn = gelu ? 224 : 128;
-  snprintf(out, (size_t)cap, "gemm_asm_%d (4 waves x 64 rows, one wave per SIMD, generated schedule) tile 256x%d, %d workgroups", wn, wn,
-           ((M + 255) / 256) * (N / wn));
-  (void)K;
+const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap) {
+  const char* tail = wn == 224 ? "gelu" : epilogue == LL_EPI_BIAS ? "bias" : epilogue == LL_EPI_BIAS_GATE_RES ? "gate_res" : "res";
+  snprintf(out, (size_t)cap, "gemm_asm_%d_%s<bf16> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", wn,
+           tail, wn, ((M + 255) / 256) * (N / wn));
   return out;
 }

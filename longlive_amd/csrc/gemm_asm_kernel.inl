@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
   unsigned long long yb = (unsigned long long)(Y + (size_t)m0 * ldo + n0), bb = (unsigned long long)(bias + n0);
   unsigned long long rb = (unsigned long long)(res ? res + (size_t)m0 * ldo + n0 : Y), gb = (unsigned long long)(gate ? gate + n0 : bias);
   unsigned ldx_b = (unsigned)ldx * 2u, ldw_b = (unsigned)K * 2u, ldo_b = (unsigned)ldo * 2u;
-  unsigned rows = (unsigned)(M - m0), cols = (unsigned)(N - n0), nk = (unsigned)(K / 32);
+  unsigned rows = (unsigned)(M - m0), cols = (unsigned)(N - n0), nk = (unsigned)(K / 64);
   unsigned flen = (unsigned)(frame_len > 0 ? frame_len : 1), gstride = (unsigned)gate_stride, um0 = (unsigned)m0;
   unsigned tid = threadIdx.x;
   asm volatile(

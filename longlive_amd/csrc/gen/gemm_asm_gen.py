@@ -12,13 +12,17 @@ tools/gfx950_emu.py in the CPU suite before any GPU run):
     Operands are swapped as in gemm.hip (A := W rows = output columns, B := X rows): a lane then owns ONE output row
     (m = lane & 31) and, per 32-column block, columns 8 g + 4 h + (0..3) -- 8-byte runs that one v_permlane32_swap per pair
     turns into 16-byte stores (T21).
-  * K-step BK = 32 (two MFMA k-steps): fragments of step k + 1 are read from LDS into the second half of a double-buffered
-    fragment file (WN / 32 + 2 ds_read_b128 per k-step and wave) while the MFMAs of step k run from the first half; every W
-    fragment feeds two MFMAs, every X fragment WN / 32.
-  * LDS: 4 slots x 32 KiB ([256 X rows | 256 W rows] x 64 B, XOR-swizzled on the SOURCE address: chunk ^ ((row >> 2) & 3)).
-    Because the fragments of step k are read during step k - 1, slot k % 4 is free again at the start of step k: the LDS-DMA of
-    step k + 4 goes there (buffer_load ... lds, 4 + 4 pieces of 1 KiB per wave and step; descriptors bound the ROWS -- rows past
-    M / N read as zeros -- and the K offset travels in soffset).  One barrier per step, counted vmcnt(16): two steps in flight.
+  * the loop runs in half-steps of 32 K (two MFMA k-steps, 2 NB x 2 MFMAs); W fragments of half-step h + 1 are read from LDS into
+    the other half of a double-buffered fragment file while the MFMAs of half-step h run; every W fragment feeds two MFMAs, every
+    X fragment WN / 32.
+  * ONLY W goes through LDS (it is what the four waves share): a ring of 5 slots of one 64-deep K-step each (WN rows x 128 B =
+    whole cache lines, XOR-swizzled on the SOURCE address: chunk ^ ((row >> 1) & 7)), staged by buffer_load ... lds four K-steps
+    ahead.  A wave's 64 X rows are its own: its X fragments come STRAIGHT from global memory into a 5-deep register ring
+    (4 buffer_load_dwordx4 per half-step, four half-steps ahead).  Descriptors bound the ROWS (rows past M / N read as zeros), the
+    K offset travels in soffset.  (The first form staged X through LDS as well, in a 4-slot ring of 32 KiB: correct, but latency-
+    bound at 15 B/clk of staging per CU -- no faster than the HIP kernels.)  vmcnt is one in-order queue: the wait at the end of
+    a half-step is counted so that the next half-step's X fragments -- and with them every W piece older than ~3 half-steps --
+    have landed; one barrier per K-step.
   * epilogues in the same text, rounding points as gemm_common.h (v = bf16(acc + bias); GELU x.sigma(2u) with v_exp / v_rcp;
     x + bf16(v . gate[frame]); x + v), packed-f32 VALU where it halves the instruction count (no MFMA runs beside it).
 """
@@ -36,87 +40,128 @@ EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_RES = 0, 1, 2, 3
 S_X, S_W, S_Y, S_BIAS, S_RES, S_GATE = 8, 10, 12, 14, 16, 18      # 64-bit bases (bytes): X row m0; W row n0; Y / RES at (m0, n0); bias + n0;
                                                                   # gate table e + gate_idx * N + n0 (row stride S_GSTRIDE per frame)
 S_LDX, S_LDW, S_LDO = 20, 21, 22                                  # row strides in bytes
-S_ROWS, S_COLS, S_NK = 23, 24, 25                                 # valid rows (M - m0), valid columns (N - n0, >= WN on this path), K / 32
+S_ROWS, S_COLS, S_NK = 23, 24, 25                                 # valid rows (M - m0), valid columns (N - n0, >= WN on this path), K / 64
 S_FLEN, S_GSTRIDE, S_M0 = 26, 27, 28                              # gate: frame_len (rows per frame), bytes between frames' gate rows, m0
 # working scalars
 S_XRS, S_WRS = 32, 36                                             # descriptors
-S_WAVE, S_I, S_KOFF, S_T0, S_T1, S_T2 = 40, 41, 42, 44, 45, 46
-S_XM0, S_WM0, S_KMAX = 47, 48, 49
+S_WAVE, S_I, S_T0, S_T1, S_T2 = 40, 41, 44, 45, 46
+S_WM0, S_XK, S_WK, S_XKMAX, S_WKMAX = 47, 48, 49, 43, 62
 S_MSK = 50                                                        # 64-bit lane masks s[50:51], s[52:53]
 V_TID = 0
 
-SLOT = lambda s: 32768 * (s & 3)
-X_REG, W_REG = 0, 16384                                           # byte offsets of the X / W regions inside a slot
+NSLOT, XU = 3, 2                                                  # W ring slots (shared, one 64-deep K-step each); X units per wave (private)
+S_XM0 = 30                                                        # LDS base of this wave's X units
+
+
+def KN(k):
+    """timing-only experiment switches (ASM_G_<k>=1; results are invalid with any of them set)"""
+    return int(os.environ.get("ASM_G_" + k, "0"))
 
 
 class Cfg:
     def __init__(self, WN, epi):
         assert WN % 32 == 0 and 64 <= WN <= 256
-        self.WN, self.NB, self.MB, self.KS, self.epi = WN, WN // 32, 2, 2, epi
+        self.WN, self.NB, self.MB, self.epi = WN, WN // 32, 2, epi
         self.nacc = self.MB * self.NB * 16
-        assert self.nacc <= 256
+        self.slotb = WN * 128                                      # bytes of one W slot: WN rows x 128 B (a 64-deep K-step)
+        self.npw = WN // 32                                        # 1-KiB LDS-DMA pieces of W per wave and K-step (WN / 8 pieces of 8 rows)
+        self.xbase = NSLOT * self.slotb                            # X units follow the W ring: wave w, unit u at xbase + (XU w + u) * xunit
+        self.xunit = 64 * 128                                      # a wave's 64 rows x 128 B
+        self.lds_bytes = self.xbase + 4 * XU * self.xunit
+        assert self.lds_bytes <= 160 * 1024
         # VGPR map
-        self.FW = 0                                               # FW[p][nb][ks] 4 regs each
-        self.FX = 2 * self.NB * self.KS * 4                       # FX[p][mb][ks]
-        nxt = self.FX + 2 * self.MB * self.KS * 4
-        self.V_WOFF, self.V_XOFF = nxt, nxt + 4                   # [ks] low-slot offsets, [2 + ks] the same + 65536
-        self.V_DX, self.V_DW = nxt + 8, nxt + 12                  # DMA source offsets (4 + 4 pieces)
-        self.V_LANE, self.V_R, self.V_H, self.V_ROW = nxt + 16, nxt + 17, nxt + 18, nxt + 19      # V_ROW[mb] -> +19, +20
-        self.V_T = nxt + 24                                       # temporaries
-        assert self.V_T + 72 <= 256, self.V_T
+        self.FW = 0                                               # FW[p][nb][ks]: 4 registers each, p = half-step parity
+        self.FX = 2 * self.NB * 2 * 4                             # FX[b][mb][ks4]: b = K-step parity, ks4 = 0..3 (a whole K-step)
+        nxt = max(self.FX + 2 * self.MB * 4 * 4, 144)             # (the epilogue's 72 temporaries + setup scratch live below)
+        self.V_WOFF = nxt                                         # [base64k][hs][ks] -> 12 registers
+        self.V_XROFF = nxt + 12                                   # [ks4] X fragment read addresses
+        self.V_DW = nxt + 16                                      # W DMA source offsets, npw <= 8 pieces
+        self.V_DX = nxt + 24                                      # X DMA source offsets, 8 pieces
+        self.V_LANE, self.V_R, self.V_H, self.V_ROW = nxt + 32, nxt + 33, nxt + 34, nxt + 35      # V_ROW[mb] -> +35, +36
+        self.V_T = 0                                              # epilogue temporaries re-use the fragment file
+        assert nxt + 37 <= 256, nxt
 
     def acc(self, mb, nb):
         return (mb * self.NB + nb) * 16
 
     def fw(self, p, nb, ks):
-        return self.FW + ((p * self.NB + nb) * self.KS + ks) * 4
+        return self.FW + ((p * self.NB + nb) * 2 + ks) * 4
 
-    def fx(self, p, mb, ks):
-        return self.FX + ((p * self.MB + mb) * self.KS + ks) * 4
+    def fx(self, b, mb, ks4):
+        return self.FX + ((b * self.MB + mb) * 4 + ks4) * 4
 
 
-def mfmas(c: Cfg, p, first):
+def mfmas(c: Cfg, h):
+    p, b, hf = h & 1, (h >> 1) & 1, h & 1
     out = []
-    for ks in range(c.KS):
+    for ks in range(2):
         for nb in range(c.NB):
             for mb in range(c.MB):
                 a = areg(c.acc(mb, nb), 16)
-                cin = "0" if (first and ks == 0) else a
-                out.append(f"v_mfma_f32_32x32x16_bf16 {a}, {vreg(c.fw(p, nb, ks), 4)}, {vreg(c.fx(p, mb, ks), 4)}, {cin}")
+                out.append(f"v_mfma_f32_32x32x16_bf16 {a}, {vreg(c.fw(p, nb, ks), 4)}, {vreg(c.fx(b, mb, 2 * hf + ks), 4)}, {a}")
     return out
 
 
-def frag_reads(c: Cfg, p, slot):
-    """fragments of one K-step from ring slot `slot` into fragment buffer p"""
-    hi = 2 if SLOT(slot) >= 65536 else 0
-    base = SLOT(slot) - (65536 if hi else 0)
+def w_frag_reads(c: Cfg, h):
+    """W fragments of half-step h (K-step h >> 1, half h & 1) from its ring slot into FW[h & 1]"""
+    slot, hs = (h >> 1) % NSLOT, h & 1
     out = []
-    for ks in range(c.KS):
-        for mb in range(c.MB):
-            out.append(f"ds_read_b128 {vreg(c.fx(p, mb, ks), 4)}, {vreg(c.V_XOFF + hi + ks)} offset:{base + X_REG + 2048 * mb}")
+    for ks in range(2):
         for nb in range(c.NB):
-            out.append(f"ds_read_b128 {vreg(c.fw(p, nb, ks), 4)}, {vreg(c.V_WOFF + hi + ks)} offset:{base + W_REG + 2048 * nb}")
+            off = slot * c.slotb + nb * 4096
+            b64, imm = off >> 16, off & 0xFFFF
+            out.append(f"ds_read_b128 {vreg(c.fw(h & 1, nb, ks), 4)}, {vreg(c.V_WOFF + 4 * b64 + 2 * hs + ks)} offset:{imm}")
     return out
 
 
-def dma_ops(c: Cfg, slot):
-    ops = []
-    for i in range(4):
-        ops.append(f"s_add_u32 m0, {sreg(S_XM0)}, {SLOT(slot) + X_REG + 1024 * i}")
-        ops.append(f"buffer_load_dwordx4 {vreg(c.V_DX + i)}, {sreg(S_XRS, 4)}, {sreg(S_KOFF)} offen lds")
-    for i in range(4):
-        ops.append(f"s_add_u32 m0, {sreg(S_WM0)}, {SLOT(slot) + W_REG + 1024 * i}")
-        ops.append(f"buffer_load_dwordx4 {vreg(c.V_DW + i)}, {sreg(S_WRS, 4)}, {sreg(S_KOFF)} offen lds")
-    ops.append(f"s_add_u32 {sreg(S_KOFF)}, {sreg(S_KOFF)}, 64")
-    ops.append(f"s_min_u32 {sreg(S_KOFF)}, {sreg(S_KOFF)}, {sreg(S_KMAX)}")       # past the last step: re-stage it (never read) instead of running off K
-    return ops
+def x_frag_reads(c: Cfg, s):
+    """the wave's X fragments of K-step s (both half-steps) from its own unit s % XU into FX[s & 1]"""
+    out = []
+    for ks4 in range(4):
+        for mb in range(c.MB):
+            out.append(f"ds_read_b128 {vreg(c.fx(s & 1, mb, ks4), 4)}, {vreg(c.V_XROFF + ks4)} offset:{(s % XU) * c.xunit + mb * 4096}")
+    return out
+
+
+def x_dma(c: Cfg, s):
+    """the wave's 64 X rows of K-step s (8 pieces of 8 rows x 128 B: whole cache lines) into its own unit s % XU"""
+    out = []
+    for i in range(8):
+        out.append(f"s_add_u32 m0, {sreg(S_XM0)}, {(s % XU) * c.xunit + 1024 * i}")
+        out.append(f"buffer_load_dwordx4 {vreg(c.V_DX + i)}, {sreg(S_XRS, 4)}, {sreg(S_XK)} offen lds")
+    out.append(f"s_add_u32 {sreg(S_XK)}, {sreg(S_XK)}, 128")
+    out.append(f"s_min_u32 {sreg(S_XK)}, {sreg(S_XK)}, {sreg(S_XKMAX)}")           # past the end: re-load the last K-step (never read)
+    return out
+
+
+def w_dma(c: Cfg, s):
+    """this wave's pieces of W K-step s into ring slot s % NSLOT"""
+    out = []
+    for i in range(c.npw):
+        out.append(f"s_add_u32 m0, {sreg(S_WM0)}, {(s % NSLOT) * c.slotb + 1024 * i}")
+        out.append(f"buffer_load_dwordx4 {vreg(c.V_DW + i)}, {sreg(S_WRS, 4)}, {sreg(S_WK)} offen lds")
+    out.append(f"s_add_u32 {sreg(S_WK)}, {sreg(S_WK)}, 128")
+    out.append(f"s_min_u32 {sreg(S_WK)}, {sreg(S_WK)}, {sreg(S_WKMAX)}")
+    return out
+
+
+def drop_loads(ops):
+    return [o for o in ops if not o.startswith("buffer_load")]
 
 
 def generate(WN: int, epi: int, prefix: str) -> str:
+    """Issue order of the staging (one in-order vmcnt queue per wave): W(j) in half-step 2 j - 5, X(j) in half-step 2 j - 4, so at
+    the END of the even half-step 2 s the wave has issued ... W(s+1) X(s+1) W(s+2) X(s+2): `s_waitcnt vmcnt(npw + 8)` there = the
+    next K-step's operands have landed.  The one barrier per K-step stands right behind that wait: it makes W(s+1) visible (first
+    read in half-step 2 s + 1, as the fragments of half-step 2 s + 2) and frees the slot of W(s) (last read in half-step 2 s),
+    which the odd half-step then refills with W(s+3).  X needs no barrier: unit (s+1) % 2 is read into FX[(s+1) & 1] in the odd
+    half-step of K-step s and refilled (X(s+3)) in the even half-step after it -- the reads are retired by the fragment waits of
+    the W reads issued after them (LDS returns in order)."""
     c = Cfg(WN, epi)
     g = Gen()
     I = g.I
-    T = c.V_T
+    T = 128                                            # setup scratch (below the address registers, inside the fragment file)
+    npw = c.npw
     # ================= setup =================
     I(f"v_and_b32 {vreg(c.V_LANE)}, 63, {vreg(V_TID)}")
     I(f"v_lshrrev_b32 {vreg(T)}, 6, {vreg(V_TID)}")
@@ -131,93 +176,115 @@ def generate(WN: int, epi: int, prefix: str) -> str:
         I(f"s_min_u32 {sreg(S_T0)}, {sreg(rows)}, 256")
         I(f"s_mul_i32 {sreg(rs + 2)}, {sreg(S_T0)}, {sreg(ld)}")
         I(f"s_mov_b32 {sreg(rs + 3)}, 0x00020000")
-    I(f"s_mov_b32 {sreg(S_KOFF)}, 0")
-    I(f"s_sub_u32 {sreg(S_KMAX)}, {sreg(S_NK)}, 1")
-    I(f"s_lshl_b32 {sreg(S_KMAX)}, {sreg(S_KMAX)}, 6")
-    I(f"s_lshl_b32 {sreg(S_XM0)}, {sreg(S_WAVE)}, 12")                     # this wave's pieces: (4 wave + i) KiB into a region
-    I(f"s_mov_b32 {sreg(S_WM0)}, {sreg(S_XM0)}")
-    # DMA source offsets: piece (4 w + i) = tile rows 16 (4 w + i) + (lane >> 2); the lane at LDS position pos = lane & 3 of its
-    # 64-byte row fetches chunk pos ^ ((row >> 2) & 3)
-    I(f"v_lshrrev_b32 {vreg(T)}, 2, {vreg(c.V_LANE)}")                     # lane >> 2
-    I(f"v_and_b32 {vreg(T + 1)}, 3, {vreg(c.V_LANE)}")                     # pos
+    I(f"s_mov_b32 {sreg(S_XK)}, 0")
+    I(f"s_mov_b32 {sreg(S_WK)}, 0")
+    I(f"s_lshl_b32 {sreg(S_WKMAX)}, {sreg(S_NK)}, 7")                      # S_NK = K / 64 (K-steps)
+    I(f"s_sub_u32 {sreg(S_WKMAX)}, {sreg(S_WKMAX)}, 128")
+    I(f"s_mov_b32 {sreg(S_XKMAX)}, {sreg(S_WKMAX)}")
+    I(f"s_mul_i32 {sreg(S_WM0)}, {sreg(S_WAVE)}, {1024 * npw}")            # this wave's W pieces inside a slot
+    I(f"s_mul_i32 {sreg(S_XM0)}, {sreg(S_WAVE)}, {XU * c.xunit}")          # this wave's X units
+    I(f"s_add_u32 {sreg(S_XM0)}, {sreg(S_XM0)}, {c.xbase}")
+    # DMA source offsets: a piece is 8 rows x 128 B, lane -> row (lane >> 3), LDS position pos = lane & 7 of the row, which
+    # fetches source chunk pos ^ ((row >> 1) & 7) (the XOR swizzle is applied on the SOURCE side; the reader undoes it)
+    I(f"v_lshrrev_b32 {vreg(T)}, 3, {vreg(c.V_LANE)}")
+    I(f"v_and_b32 {vreg(T + 1)}, 7, {vreg(c.V_LANE)}")
+    for dst, cnt, ld in ((c.V_DW, npw, S_LDW), (c.V_DX, 8, S_LDX)):
+        I(f"s_mul_i32 {sreg(S_T0)}, {sreg(S_WAVE)}, {8 * cnt}")            # first row of this wave's pieces
+        for i in range(cnt):
+            I(f"v_add_u32 {vreg(T + 2)}, {sreg(S_T0)}, {vreg(T)}")
+            I(f"v_add_u32 {vreg(T + 2)}, {8 * i}, {vreg(T + 2)}")          # row within the tile
+            I(f"v_lshrrev_b32 {vreg(T + 3)}, 1, {vreg(T + 2)}")
+            I(f"v_and_b32 {vreg(T + 3)}, 7, {vreg(T + 3)}")
+            I(f"v_xor_b32 {vreg(T + 3)}, {vreg(T + 3)}, {vreg(T + 1)}")
+            I(f"v_lshlrev_b32 {vreg(T + 3)}, 4, {vreg(T + 3)}")
+            I(f"v_mul_lo_u32 {vreg(dst + i)}, {vreg(T + 2)}, {sreg(ld)}")
+            I(f"v_add_u32 {vreg(dst + i)}, {vreg(dst + i)}, {vreg(T + 3)}")
+    # rows of this lane (epilogue addressing, idle test)
     I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_WAVE)}, 6")                       # 64 w
-    for i in range(4):
-        I(f"v_add_u32 {vreg(T + 2)}, {sreg(S_T0)}, {vreg(T)}")
-        I(f"v_add_u32 {vreg(T + 2)}, {16 * i}, {vreg(T + 2)}")             # row within the 256-row region
-        I(f"v_lshrrev_b32 {vreg(T + 3)}, 2, {vreg(T + 2)}")
-        I(f"v_and_b32 {vreg(T + 3)}, 3, {vreg(T + 3)}")
-        I(f"v_xor_b32 {vreg(T + 3)}, {vreg(T + 3)}, {vreg(T + 1)}")
-        I(f"v_lshlrev_b32 {vreg(T + 3)}, 4, {vreg(T + 3)}")
-        I(f"v_mul_lo_u32 {vreg(c.V_DX + i)}, {vreg(T + 2)}, {sreg(S_LDX)}")
-        I(f"v_add_u32 {vreg(c.V_DX + i)}, {vreg(c.V_DX + i)}, {vreg(T + 3)}")
-        I(f"v_mul_lo_u32 {vreg(c.V_DW + i)}, {vreg(T + 2)}, {sreg(S_LDW)}")
-        I(f"v_add_u32 {vreg(c.V_DW + i)}, {vreg(c.V_DW + i)}, {vreg(T + 3)}")
-    # prologue staging: steps 0..3 into slots 0..3
-    for st in range(4):
-        for op in dma_ops(c, st):
-            I(op)
-    # idle waves (their 64 rows are all past M) only stage and synchronise
-    I(f"s_cmp_ge_u32 {sreg(S_T0)}, {sreg(S_ROWS)}")
-    I(f"s_cbranch_scc1 {prefix}_IDLE")
-    # fragment read offsets: row r (+ 32 blocks by immediate), chunk (2 ks + h) ^ ((r >> 2) & 3); X rows start at 64 w
-    I(f"v_lshrrev_b32 {vreg(T)}, 2, {vreg(c.V_R)}")
-    I(f"v_and_b32 {vreg(T)}, 3, {vreg(T)}")
-    I(f"v_lshlrev_b32 {vreg(T + 1)}, 6, {vreg(c.V_R)}")                    # r * 64
-    I(f"s_lshl_b32 {sreg(S_T1)}, {sreg(S_WAVE)}, 12")                      # 64 w rows * 64 B
-    for ks in range(c.KS):
-        I(f"v_add_u32 {vreg(T + 2)}, {2 * ks}, {vreg(c.V_H)}")
-        I(f"v_xor_b32 {vreg(T + 2)}, {vreg(T + 2)}, {vreg(T)}")
-        I(f"v_lshl_add_u32 {vreg(c.V_WOFF + ks)}, {vreg(T + 2)}, 4, {vreg(T + 1)}")
-        I(f"v_add_u32 {vreg(c.V_XOFF + ks)}, {sreg(S_T1)}, {vreg(c.V_WOFF + ks)}")
-        I(f"v_add_u32 {vreg(c.V_WOFF + 2 + ks)}, 0x10000, {vreg(c.V_WOFF + ks)}")
-        I(f"v_add_u32 {vreg(c.V_XOFF + 2 + ks)}, 0x10000, {vreg(c.V_XOFF + ks)}")
     for mb in range(c.MB):
         I(f"v_add_u32 {vreg(c.V_ROW + mb)}, {sreg(S_T0)}, {vreg(c.V_R)}")
         if mb:
             I(f"v_add_u32 {vreg(c.V_ROW + mb)}, {32 * mb}, {vreg(c.V_ROW + mb)}")
+    # fragment read offsets: row r (+ 32 per block by immediate), chunk at position chunk ^ ((r >> 1) & 7)
+    I(f"v_lshrrev_b32 {vreg(T)}, 1, {vreg(c.V_R)}")
+    I(f"v_and_b32 {vreg(T)}, 7, {vreg(T)}")
+    I(f"v_lshlrev_b32 {vreg(T + 1)}, 7, {vreg(c.V_R)}")                    # r * 128
+    for hs in range(2):
+        for ks in range(2):
+            I(f"v_add_u32 {vreg(T + 2)}, {4 * hs + 2 * ks}, {vreg(c.V_H)}")
+            I(f"v_xor_b32 {vreg(T + 2)}, {vreg(T + 2)}, {vreg(T)}")
+            I(f"v_lshl_add_u32 {vreg(c.V_WOFF + 2 * hs + ks)}, {vreg(T + 2)}, 4, {vreg(T + 1)}")
+            I(f"v_add_u32 {vreg(c.V_WOFF + 4 + 2 * hs + ks)}, 0x10000, {vreg(c.V_WOFF + 2 * hs + ks)}")
+            I(f"v_add_u32 {vreg(c.V_WOFF + 8 + 2 * hs + ks)}, 0x20000, {vreg(c.V_WOFF + 2 * hs + ks)}")
+            I(f"v_add_u32 {vreg(c.V_XROFF + 2 * hs + ks)}, {sreg(S_XM0)}, {vreg(c.V_WOFF + 2 * hs + ks)}")     # same row / chunk, own unit
+    # prologue staging in the loop's own issue order: W(0) X(0) W(1) X(1) W(2)
+    I(f"s_cmp_ge_u32 {sreg(S_T0)}, {sreg(S_ROWS)}")                        # idle waves (their 64 rows are all past M) stage W only
+    I(f"s_cbranch_scc1 {prefix}_IDLE")
+    for j in range(NSLOT):
+        for op in w_dma(c, j):
+            I(op)
+        if j < XU:
+            for op in x_dma(c, j):
+                I(op)
     for r in range(c.nacc):                            # accumulators start from zero (while the first tiles fly)
         I(f"v_accvgpr_write_b32 {areg(r)}, 0")
-    I("s_waitcnt vmcnt(24)")                           # step 0 has landed (3 later steps = 24 pieces may fly)
-    I("s_barrier")                                     # (1)
-    for op in frag_reads(c, 0, 0):
+    I(f"s_waitcnt vmcnt({2 * npw + 8})")               # W(0), X(0) have landed
+    I("s_barrier")
+    for op in x_frag_reads(c, 0) + w_frag_reads(c, 0):
         I(op)
-    I("s_waitcnt vmcnt(16)")                           # step 1 has landed
-    I("s_barrier")                                     # (2) every wave has read slot 0: step 4 may be staged into it
+    I("s_waitcnt lgkmcnt(0)")
     I(f"s_mov_b32 {sreg(S_I)}, 0")
-    # ================= main loop: step k computes from fragment buffer k & 1, reads step k + 1 (slot (k + 1) & 3) into the other,
-    # stages step k + 4 into slot k & 3.  Unrolled by 4.
+    # ================= main loop over half-steps, unrolled over lcm(NSLOT, XU) K-steps =================
+    period = 2 * NSLOT * XU // (2 if NSLOT % 2 == 0 else 1)
+    assert (period // 2) % NSLOT == 0 and (period // 2) % XU == 0
     g.L(f"{prefix}_LOOP")
-    for u in range(4):
-        p = u & 1
-        fillers = [(0.6 + k * (len(mfmas(c, p, False)) - 8) / (c.NB * 2 + 4), op) for k, op in enumerate(frag_reads(c, p ^ 1, u + 1))]
-        fillers += spread(dma_ops(c, u), 2.3, len(mfmas(c, p, False)) - 1.5)
-        g.phase(mfmas(c, p, False), fillers)
-        I("s_waitcnt vmcnt(16)")                       # all but the last two steps' pieces have landed: step k + 2 is in LDS
-        I("s_barrier")
-        I(f"s_add_u32 {sreg(S_I)}, {sreg(S_I)}, 1")
-        I(f"s_cmp_ge_u32 {sreg(S_I)}, {sreg(S_NK)}")
-        I(f"s_cbranch_scc1 {prefix}_EPI")
+    for h in range(period):
+        s = h >> 1
+        mm = mfmas(c, h)
+        n = len(mm)
+        wr = [] if KN("NO_WREAD") else w_frag_reads(c, h + 1)
+        if h & 1 == 0:
+            fillers = [(0.6 + k * (n - 6) / len(wr), op) for k, op in enumerate(wr)] if wr else []
+            xd = x_dma(c, s + 2)
+            fillers += spread(drop_loads(xd) if KN("NO_X") else xd, 1.3, n - 1.5)
+            g.phase([] if KN("NO_MFMA") else mm, fillers)
+            I(f"s_waitcnt vmcnt({npw + 8})")           # W(s+1), X(s+1) have landed (younger: W(s+2), X(s+2))
+            I("s_barrier")                             # W(s+1) visible to all; every wave is done reading the slot of W(s)
+        else:
+            xr = [] if KN("NO_WREAD") else x_frag_reads(c, s + 1)
+            fillers = [(0.3 + k * 0.5, op) for k, op in enumerate(xr)]                   # ahead of the W reads: retired with them
+            fillers += [(4.6 + k * (n - 10) / len(wr), op) for k, op in enumerate(wr)] if wr else []
+            wd = w_dma(c, s + 3)
+            fillers += spread(drop_loads(wd) if KN("NO_W") else wd, 1.3, n - 1.5)
+            g.phase([] if KN("NO_MFMA") else mm, fillers)
+            I(f"s_add_u32 {sreg(S_I)}, {sreg(S_I)}, 1")
+            I(f"s_cmp_ge_u32 {sreg(S_I)}, {sreg(S_NK)}")
+            I(f"s_cbranch_scc1 {prefix}_EPI")
     I(f"s_branch {prefix}_LOOP")
     # ================= epilogue =================
     g.L(f"{prefix}_EPI")
     I("s_nop 15")
     I("s_nop 15")
+    if KN("NO_EPI"):
+        I("s_waitcnt vmcnt(0)")
+        I("s_endpgm")
     gen_epilogue(g, c)
     I("s_waitcnt vmcnt(0)")
     I("s_endpgm")
-    # ================= idle waves =================
+    # ================= idle waves: their share of W, the barriers =================
     g.L(f"{prefix}_IDLE")
-    I("s_waitcnt vmcnt(24)")
-    I("s_barrier")
-    I("s_waitcnt vmcnt(16)")
+    for j in range(NSLOT):
+        for op in w_dma(c, j):
+            I(op)
+    I(f"s_waitcnt vmcnt({2 * npw})")
     I("s_barrier")
     I(f"s_mov_b32 {sreg(S_I)}, 0")
     g.L(f"{prefix}_IDLE_LOOP")
-    for u in range(4):
-        for op in dma_ops(c, u):
-            I(op)
-        I("s_waitcnt vmcnt(16)")
+    for st in range(NSLOT):
+        I(f"s_waitcnt vmcnt({npw})")
         I("s_barrier")
+        for op in w_dma(c, st + 3):
+            I(op)
         I(f"s_add_u32 {sreg(S_I)}, {sreg(S_I)}, 1")
         I(f"s_cmp_ge_u32 {sreg(S_I)}, {sreg(S_NK)}")
         I(f"s_cbranch_scc1 {prefix}_IDLE_END")
@@ -226,6 +293,7 @@ def generate(WN: int, epi: int, prefix: str) -> str:
     I("s_waitcnt vmcnt(0)")
     I("s_endpgm")
     return finalize(g.out)
+
 
 
 def gen_epilogue(g: Gen, c: Cfg):
@@ -249,9 +317,11 @@ def gen_epilogue(g: Gen, c: Cfg):
     I(f"v_lshlrev_b32 {vreg(T + 62)}, 3, {vreg(c.V_H)}")                     # bias / gate column byte offset of this half: 8 h
     if epi == EPI_GATE_RES:
         # gate row of the lane's row: frame = (m0 + row) / frame_len  (integer division via float with one correction each way)
-        for mb in range(c.MB):
+        I(f"s_sub_u32 {sreg(S_T1)}, {sreg(S_ROWS)}, 1")                      # rows past M take the last valid row's frame (gemm_common.h: mc = min(m, M - 1)):
+        for mb in range(c.MB):                                               # their gate address must stay inside the table
             m, q, t = T + 66, T + 64 + mb, T + 48
-            I(f"v_add_u32 {vreg(m)}, {sreg(S_M0)}, {vreg(c.V_ROW + mb)}")
+            I(f"v_min_u32 {vreg(m)}, {sreg(S_T1)}, {vreg(c.V_ROW + mb)}")
+            I(f"v_add_u32 {vreg(m)}, {sreg(S_M0)}, {vreg(m)}")
             I(f"v_cvt_f32_u32 {vreg(t)}, {vreg(m)}")
             I(f"v_cvt_f32_u32 {vreg(t + 1)}, {sreg(S_FLEN)}")
             I(f"v_rcp_f32 {vreg(t + 1)}, {vreg(t + 1)}")

@@ -1,6 +1,6 @@
 """The generated GEMM kernels (longlive_amd/csrc/gen/gemm_asm_gen.py) executed on the CPU by tools/gfx950_emu.py: one workgroup
 (a 256 x WN tile with a ragged M edge, idle waves included) for every epilogue, against a numpy restatement of gemm_common.h's
-rounding points; both completion models of the emulator; lint clean; assembles for gfx950."""
+rounding points; all three completion models of the emulator; lint clean; assembles for gfx950."""
 import os
 import subprocess
 import sys
@@ -28,7 +28,7 @@ def rbf(x):
     return f32(bf(x))
 
 
-def run_case(WN, epi, mode, rows_valid=200, K=160, seed=0, m0=300, frame_len=130):
+def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130):
     rng = np.random.default_rng(seed)
     text = G.generate(WN, epi, f"T{WN}E{epi}")
     assert G.lint(text) == []
@@ -37,19 +37,19 @@ def run_case(WN, epi, mode, rows_valid=200, K=160, seed=0, m0=300, frame_len=130
     w = bf(rng.standard_normal((N, K)) / np.sqrt(K))
     bias = bf(0.1 * rng.standard_normal(N))
     res = bf(rng.standard_normal((rows_valid, N)))
-    nframes = (m0 + rows_valid + frame_len - 1) // frame_len + 1
+    nframes = (m0 + rows_valid - 1) // frame_len + 1      # exactly the frames the valid rows touch: rows past M must not index beyond them
     gate = bf(0.5 * rng.standard_normal((nframes, N)))
     mem = E.Memory()
     ax, aw, ab, ar, ag = mem.alloc(x), mem.alloc(w), mem.alloc(bias), mem.alloc(res), mem.alloc(gate)
     ay = mem.alloc(np.full((rows_valid, N), 0x7FC0, dtype=np.uint16))
-    m = E.Machine(text, mem, 4, mode=mode, lds_bytes=128 * 1024)
+    m = E.Machine(text, mem, 4, mode=mode, lds_bytes=G.Cfg(WN, epi).lds_bytes)
     for wv in m.waves:
         s = wv.s
         def put64(i, val):
             s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
         put64(G.S_X, ax); put64(G.S_W, aw); put64(G.S_Y, ay); put64(G.S_BIAS, ab); put64(G.S_RES, ar); put64(G.S_GATE, ag)
         s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K * 2, K * 2, N * 2
-        s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 32
+        s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 64
         s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
         wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
         wv.v[1:] = 0x7FC0BEEF
@@ -86,7 +86,20 @@ def test_gemm_asm_epilogues(epi):
 
 
 def test_gemm_asm_eager_model_and_small_tile():
-    got, want = run_case(128, G.EPI_BIAS, "eager", rows_valid=70, K=96)
+    got, want = run_case(128, G.EPI_BIAS, "eager", rows_valid=70, K=832)
+    assert (got == want).mean() > 0.97 and np.abs(got - want).max() < 0.05
+
+
+def test_gemm_asm_mixed_model_catches_no_early_refill():
+    """LDS-DMA lands at once, LDS reads only when waited for: a ring slot / unit refilled before its fragment reads have been
+    retired would show here (the X units are wave-private and guarded by lgkmcnt order alone, not by a barrier)."""
+    got, want = run_case(224, G.EPI_BIAS, "mixed", rows_valid=256, K=1024)
+    assert (got == want).mean() > 0.97 and np.abs(got - want).max() < 0.05
+
+
+def test_gemm_asm_widest_tile_fills_the_lds():
+    assert G.Cfg(256, G.EPI_RES).lds_bytes == 160 * 1024
+    got, want = run_case(256, G.EPI_RES, "lazy", rows_valid=130, K=512)
     assert (got == want).mean() > 0.97 and np.abs(got - want).max() < 0.05
 
 

@@ -196,6 +196,16 @@ def _set_tuning(key, value):
     _lib.check(_lib.load().ll_set_tuning(key.encode(), int(value)), "ll_set_tuning")
 
 
+@pytest.fixture
+def splitk_kernel():
+    """The shipped tuning (gemm_asm = 3) sends split-K calls the generated 256 x 128 kernel covers to that kernel; the tests of the
+    split-K kernel itself (gemm_kernel_v4sk: hand-off, epochs, fail-safe wait) against the HIP kernels switch the generated kernels
+    off for their duration."""
+    _set_tuning("gemm_asm", 0)
+    yield
+    _set_tuning("gemm_asm", 3)
+
+
 @pytest.mark.parametrize("B,Lq,H,Sk,seg,W", [
     (2, 300, 3, 1500, (0, 1437), 5),      # 12 pairs x 23 tiles over 5 workgroups: whole pairs + head / tail parts, ragged keys
     (2, 300, 3, 1500, (0, 1437), 40),     # more workgroups than pairs: every pair cut into 3-4 parts (middle parts too)
@@ -490,7 +500,7 @@ def test_qkv_projection_with_v_insert_is_bit_identical(ops, B, F, hp, wp, H, K, 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4680, 1536, 8960, "gate"), (4680, 1536, 8960, "bias"), (1560, 1536, 8960, "res"),
                                        (300, 512, 1024, "gelu"), (4680, 1536, 1536, "bias"), (300, 136, 1024, "bias")])
-def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
+def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi, splitk_kernel):
     """ll_gemm_bf16_splitk (256 x 256 tiles, K cut in two, halves exchanged through the workspace inside the kernel) against
     ll_gemm_bf16: same products, the fp32 sum split once more -> <= 1 bf16 ulp apart; 30 repeated launches are bit-identical
     (a stale or torn hand-off would show up as a run-to-run difference) and leave the workspace's error word at zero."""
@@ -527,8 +537,8 @@ def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4680, 8960, 1536, "gelu"), (4680, 1536, 1536, "gate"), (4680, 1536, 1536, "res"),
-                                       (4680, 1536, 1536, "bias"), (4680, 1536, 8960, "gate"), (300, 224, 128, "gelu"),
-                                       (70, 128, 192, "bias"), (9360, 1536, 1536, "gate"), (513, 448, 192, "gelu")])
+                                       (4680, 1536, 1536, "bias"), (4680, 1536, 8960, "gate"), (300, 224, 256, "gelu"),
+                                       (70, 128, 256, "bias"), (9360, 1536, 1536, "gate"), (513, 448, 320, "gelu")])
 def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
     """The generated one-wave-per-SIMD GEMM kernels (tuning key gemm_asm; gen/gemm_asm_gen.py) against the HIP kernels they replace,
     at the block linears' shapes (FFN1, O / cross-o / cross-q, FFN2, B = 2) and at ragged edges: same products, the fp32 sum taken in
@@ -543,16 +553,20 @@ def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
     if epi == "gate":
         F_ = 3 if M % 3 == 0 else 1
         kw.update(e=hn("ge", (1, F_, 6, N), 0.5).to(DEV), mod=None, gate_idx=5, rows_per_batch=M, frame_len=M // F_)
-    want = ops.gemm(x, w, b, code, **kw)
+    from longlive_amd import _lib
+    import ctypes as C
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.load().ll_gemm_plan_epi(M, N, K, 0, code, 1, 0, buf, 256), "plan")
+    assert b"gemm_asm_" in buf.value, buf.value           # the shipped tuning takes the generated kernel for this call
     try:
-        _set_tuning("gemm_asm", 1)
-        from longlive_amd import _lib
-        import ctypes as C
-        buf = C.create_string_buffer(256)
-        got = ops.gemm(x, w, b, code, **kw)
-        again = ops.gemm(x, w, b, code, **kw)
-    finally:
         _set_tuning("gemm_asm", 0)
+        _lib.check(_lib.load().ll_gemm_plan_epi(M, N, K, 0, code, 1, 0, buf, 256), "plan")
+        assert b"gemm_kernel_v" in buf.value, buf.value
+        want = ops.gemm(x, w, b, code, **kw)
+    finally:
+        _set_tuning("gemm_asm", 3)
+    got = ops.gemm(x, w, b, code, **kw)
+    again = ops.gemm(x, w, b, code, **kw)
     assert torch.equal(got, again)
     fused = epi in ("gate", "res")
     assert_bf16_close(got, want, 2, 0.97, f"gemm_asm {M}x{N}x{K} {epi}", atol=4e-2 if fused else None)
@@ -562,7 +576,7 @@ def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
             assert rel_l2(got.cpu(), ref) < 4e-3
 
 
-def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
+def test_gemm_splitk_handoff_is_fresh_across_launches(ops, splitk_kernel):
     """The partial tiles live at fixed workspace addresses: alternate two different activations so that a partner reading the
     PREVIOUS launch's bytes (a stale line somewhere between the two workgroups) cannot reproduce the right answer."""
     M, N, K = 4680, 1536, 8960
@@ -587,7 +601,7 @@ def test_gemm_splitk_handoff_is_fresh_across_launches(ops):
     torch.cuda.synchronize()
 
 
-def test_gemm_splitk_handoff_is_fail_safe(ops):
+def test_gemm_splitk_handoff_is_fail_safe(ops, splitk_kernel):
     """The hand-off never hangs and never trusts a stale word: (1) a flag page full of garbage (what an aborted launch or a foreign
     writer could leave behind) changes nothing -- flags must equal THIS launch's epoch; (2) with the test hook that makes every
     second workgroup exit before it publishes (a partner that never arrives), the launch still completes within the bounded poll,
@@ -622,7 +636,7 @@ def test_gemm_splitk_handoff_is_fail_safe(ops):
     ops.splitk_check()
 
 
-def test_gemm_splitk_l2_exchange_matches(ops):
+def test_gemm_splitk_l2_exchange_matches(ops, splitk_kernel):
     """Opt-in exchange through the pair's L2 (tuning key gemm_splitk_l2; falls back to the sc1 form when the placement probe says
     partners do not share an XCD): same bits as the shipped exchange."""
     from longlive_amd import _lib

@@ -11,10 +11,12 @@ What it models:
   * MFMA lane layouts as documented for gfx950 (cdna_hip_programming.md section 3): v_mfma_f32_32x32x16_bf16, v_mfma_f32_16x16x32_bf16
   * LDS (160 KiB) with ds_read_b128 / _b64 / ds_read_b64_tr_b16 / ds_write_*; LDS-DMA (buffer_load_dwordx4 ... lds,
     global_load_lds_dwordx4: destination = M0 base + instruction offset + 16 x lane)
-  * asynchronous completion in TWO modes, both of which a correct kernel must survive:
+  * asynchronous completion in THREE modes, all of which a correct kernel must survive:
       eager : every memory operation completes at issue          (catches write-after-read races on LDS ring slots)
       lazy  : an operation completes only when an s_waitcnt retires it; until then a register destination holds a NaN poison
               and an LDS-DMA destination keeps its old bytes        (catches missing / under-counted waits)
+      mixed : vector-memory operations (LDS-DMA included) complete at issue, LDS reads only when retired (catches an LDS-DMA
+              overwriting a ring slot whose fragment reads have been issued but not waited for)
     vmcnt counts VMEM loads, stores and LDS-DMA together in issue order; lgkmcnt counts LDS operations in issue order
   * a static check of software-visible hazards is NOT done here (see attn_asm_gen.lint): the emulator has no notion of wait states.
 
@@ -210,7 +212,7 @@ class Wave:
 
 class Machine:
     def __init__(self, program_text: str, mem: Memory, nwaves: int, mode: str = "lazy", lds_bytes: int = 160 * 1024):
-        assert mode in ("lazy", "eager")
+        assert mode in ("lazy", "eager", "mixed")
         self.insts, self.labels = parse_program(program_text)
         self.mem, self.mode = mem, mode
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
@@ -278,7 +280,7 @@ class Machine:
 
     # ---- async queues -----------------------------------------------------------------------------------------------
     def _issue(self, w: Wave, q: str, fn):
-        if self.mode == "eager":
+        if self.mode == "eager" or (self.mode == "mixed" and q == "vm"):
             fn()
             getattr(w, q).append(None)
         else:

@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
       if (skb > 0) { CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb)); }
     }
     if (skws) fn = [=]() { LL(ll_gemm_bf16_splitk(x, w, b, out, M, N, K, K, N, epi, res, e, mod, 6, 2, M, M / 3, skws, skb, s)); };
-    else fn = [=]() { LL(ll_gemm_bf16(x, w, b, out, M, N, K, K, N, epi, res, e, mod, 6, 2, M, M / 3, s)); };
+    else fn = [=]() { LL(ll_gemm_bf16(x, w, b, out, M, N, K, K, N, epi, res, e, getenv("KENERGY_MOD") ? mod : nullptr, 6, 2, M, M / 3, s)); };
     flops = 2.0 * M * N * K;
   }
   for (int i = 0; i < 10; ++i) fn();
