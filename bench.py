@@ -599,18 +599,18 @@ def run_replica(args, rank, world, local_rank, sync):
         s = ktimer.summary()["flash_attn_self"]
         achieved = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
         traffic, src = None, None
-        for name in ("r02_attn_pmc.json", "attn_pmc.json"):
-            pmc = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                    src = (f"profiles/{name}: rocprofv3 --pmc passes over tools/kbench on the same kernel and shape "
-                           "(TCC_EA0_RDREQ/WRREQ, gfx950 x2 read correction); NOT measured in this run")
-                    break
-                except Exception:
-                    traffic = None
-        res["roofline"] = {"bound": "mfma", "kernel": _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1, 1)
-                           + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,
+        plan_now = _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1, 1)
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_inpipe.json")   # counters of the SAME kernel in the pipeline's launch order
+        if os.path.exists(pmc) and "flash_attn_asm_kernel" in plan_now:
+            try:
+                row = [k for k in json.load(open(pmc))["kernels"] if "flash_attn_asm_kernel" in k["kernel"]][0]
+                traffic = row["fabric_bytes_per_launch"]
+                src = ("profiles/r03_pmc_inpipe.json: rocprofv3 --pmc passes over tools/kbench layerseq (the layer's 13 launches in "
+                       "model order) on this kernel and shape (TCC_EA0_RDREQ / _32B / TCC_BUBBLE, TCC_EA0_WRREQ / _64B; gfx950 x2 read "
+                       "correction); NOT measured in this run (rocprofv3 --pmc over a torch process segfaults here)")
+            except Exception:
+                traffic = None
+        res["roofline"] = {"bound": "mfma", "kernel": plan_now + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,
                            "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_source": src, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
                            "flop_per_launch": s["work_per_launch"], "share_of_step": s["total_ms"] / (1e3 * elapsed),

@@ -341,92 +341,106 @@ def gen_epilogue(g: Gen, c: Cfg):
             I(f"v_lshl_add_u32 {vreg(q)}, {vreg(c.V_H)}, 3, {vreg(q)}")      # + 8 h: the gate is applied in the accumulator layout (as the bias)
     for mb in range(c.MB):
         I(f"v_cmp_lt_u32_e64 {sreg(S_MSK + 2 * mb, 2)}, {vreg(c.V_ROW + mb)}, {sreg(S_ROWS)}")
-    for nb in range(c.NB):
-        # bias of this column block: lane needs columns 32 nb + 8 g4 + 4 h + (0..3): 4 loads of 8 bytes
+    # Every global read of the epilogue is issued ahead of its use (one exposed latency per kernel, not one per block): all bias
+    # vectors first, then the gate / residual pieces of block j + 1 while block j computes (two buffers of 16 registers).
+    BB, PB = T + 72, T + 72 + 8 * c.NB                                       # bias raw [nb][g4] (2 registers each); block buffers P[2][16]
+    assert PB + 32 <= min(c.V_WOFF + 32, 256), (PB, c.V_WOFF)               # below the registers that survive the loop (V_LANE ...)
+    for nb in range(c.NB):                                                   # lane needs columns 32 nb + 8 g4 + 4 h + (0..3): 4 loads of 8 bytes
         for g4 in range(4):
-            I(f"global_load_dwordx2 {vreg(T + 40 + 2 * g4, 2)}, {vreg(T + 62)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
-        I("s_waitcnt vmcnt(0)")
-        for g4 in range(4):                                                  # bf16 x4 -> f32 x4: T+24+4 g4 .. +3
-            for d in range(2):
-                src = T + 40 + 2 * g4 + d
-                I(f"v_lshlrev_b32 {vreg(T + 24 + 4 * g4 + 2 * d)}, 16, {vreg(src)}")
-                I(f"v_and_b32 {vreg(T + 24 + 4 * g4 + 2 * d + 1)}, 0xffff0000, {vreg(src)}")
-        for mb in range(c.MB):
-            a0 = c.acc(mb, nb)
-            # v = bf16(acc + bias), kept as f32 in T+0..15
-            for r in range(16):
-                I(f"v_accvgpr_read_b32 {vreg(T + r)}, {areg(a0 + r)}")
-            for r in range(0, 16, 2):
-                I(f"v_pk_add_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 24 + r, 2)}")
-            for r in range(0, 16, 2):                                        # round to bf16 and back
-                I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
-            if epi in (EPI_GELU, EPI_GATE_RES):
-                for r in range(0, 16, 2):
-                    I(f"v_lshlrev_b32 {vreg(T + r)}, 16, {vreg(T + 16 + r // 2)}")
-                    I(f"v_and_b32 {vreg(T + r + 1)}, 0xffff0000, {vreg(T + 16 + r // 2)}")
-            if epi == EPI_GATE_RES:                                          # w = bf16(v * gate[frame][n]) in the accumulator layout
-                for g4 in range(4):
-                    I(f"global_load_dwordx2 {vreg(T + 48 + 2 * g4, 2)}, {vreg(T + 64 + mb)}, {sreg(S_GATE, 2)} offset:{64 * nb + 16 * g4}")
-                I("s_waitcnt vmcnt(0)")
-                for r in range(0, 16, 2):
-                    src = T + 48 + r // 2
-                    I(f"v_lshlrev_b32 {vreg(T + 56)}, 16, {vreg(src)}")
-                    I(f"v_and_b32 {vreg(T + 57)}, 0xffff0000, {vreg(src)}")
-                    I(f"v_pk_mul_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 56, 2)}")
-                for r in range(0, 16, 2):
-                    I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
-            if epi == EPI_GELU:
-                # y = x * rcp(1 + exp2(ce * (k0 * (x + ((k1 * x) * x) * x))))   (gemm_common.h / common.h gelu_tanh, contraction off)
-                for r in range(0, 16, 2):
-                    x, t = vreg(T + r, 2), vreg(T + 44 + (r % 4), 2)
-                    I(f"v_pk_mul_f32 {t}, {sreg(cons['k1'], 2)}, {x}")
-                    I(f"v_pk_mul_f32 {t}, {t}, {x}")
-                    I(f"v_pk_mul_f32 {t}, {t}, {x}")
-                    I(f"v_pk_add_f32 {t}, {x}, {t}")
-                    I(f"v_pk_mul_f32 {t}, {sreg(cons['k0'], 2)}, {t}")
-                    I(f"v_pk_mul_f32 {t}, {sreg(cons['ce'], 2)}, {t}")
-                    I(f"v_exp_f32 {vreg(T + 44 + (r % 4))}, {vreg(T + 44 + (r % 4))}")
-                    I(f"v_exp_f32 {vreg(T + 45 + (r % 4))}, {vreg(T + 45 + (r % 4))}")
-                    I("s_nop 0")                                             # transcendental result -> VALU: one wait state
-                    I(f"v_pk_add_f32 {t}, {sreg(cons['one'], 2)}, {t}")
-                    I(f"v_rcp_f32 {vreg(T + 44 + (r % 4))}, {vreg(T + 44 + (r % 4))}")
-                    I(f"v_rcp_f32 {vreg(T + 45 + (r % 4))}, {vreg(T + 45 + (r % 4))}")
-                    I("s_nop 0")
-                    I(f"v_pk_mul_f32 {x}, {x}, {t}")
-                for r in range(0, 16, 2):
-                    I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
-            # packed bf16 in T+16..23: dwords (2 g4, 2 g4 + 1) = columns 8 g4 + 4 h + (0..3).  T21: swap pairs (g4 = 0,1) and (2,3)
+            I(f"global_load_dwordx2 {vreg(BB + 8 * nb + 2 * g4, 2)}, {vreg(T + 62)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
+    blocks = [(nb, mb) for nb in range(c.NB) for mb in range(c.MB)]
+    nl = {EPI_GATE_RES: 6, EPI_RES: 2}.get(epi, 0)                           # loads per block
+
+    def block_loads(j):
+        nb, mb = blocks[j]
+        P = PB + 16 * (j & 1)
+        if epi == EPI_GATE_RES:                                              # gate[frame][n] in the accumulator layout (as the bias)
+            for g4 in range(4):
+                I(f"global_load_dwordx2 {vreg(P + 2 * g4, 2)}, {vreg(T + 64 + mb)}, {sreg(S_GATE, 2)} offset:{64 * nb + 16 * g4}")
+        if epi in (EPI_GATE_RES, EPI_RES):                                   # residual in the 8-column layout after the swap
+            I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
             for k in (0, 2):
-                ax, ay, bx, by = T + 16 + 2 * k, T + 17 + 2 * k, T + 18 + 2 * k, T + 19 + 2 * k
-                I("s_nop 1")
-                I(f"v_permlane32_swap_b32 {vreg(ax)}, {vreg(bx)}")
-                I(f"v_permlane32_swap_b32 {vreg(ay)}, {vreg(by)}")
-            off_y = 64 * nb
-            if epi in (EPI_BIAS, EPI_GELU):
-                I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
-                for k in (0, 2):
-                    I(f"global_store_dwordx4 {vreg(T + 60 + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
-                I("s_mov_b64 exec, -1")
-            else:
-                # residual arithmetic in the 8-column layout after the swap: out = bf16(res + w), w = v or bf16(v * gate)
-                I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
-                for k in (0, 2):
-                    I(f"global_load_dwordx4 {vreg(T + 40 + 2 * k, 4)}, {vreg(T + 60 + mb)}, {sreg(S_RES, 2)} offset:{off_y + 16 * k}")
-                I("s_mov_b64 exec, -1")
-                I("s_waitcnt vmcnt(0)")
-                for k in (0, 2):
-                    for d in range(4):                                       # 8 columns: res + v in f32, rounded once
-                        vsrc, rsrc = T + 16 + 2 * k + d, T + 40 + 2 * k + d
-                        I(f"v_lshlrev_b32 {vreg(T)}, 16, {vreg(vsrc)}")
-                        I(f"v_and_b32 {vreg(T + 1)}, 0xffff0000, {vreg(vsrc)}")
-                        I(f"v_lshlrev_b32 {vreg(T + 2)}, 16, {vreg(rsrc)}")
-                        I(f"v_and_b32 {vreg(T + 3)}, 0xffff0000, {vreg(rsrc)}")
-                        I(f"v_pk_add_f32 {vreg(T, 2)}, {vreg(T + 2, 2)}, {vreg(T, 2)}")
-                        I(f"v_cvt_pk_bf16_f32 {vreg(vsrc)}, {vreg(T)}, {vreg(T + 1)}")
-                I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
-                for k in (0, 2):
-                    I(f"global_store_dwordx4 {vreg(T + 60 + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
-                I("s_mov_b64 exec, -1")
+                I(f"global_load_dwordx4 {vreg(P + 8 + 2 * k, 4)}, {vreg(T + 60 + mb)}, {sreg(S_RES, 2)} offset:{64 * nb + 16 * k}")
+            I("s_mov_b64 exec, -1")
+
+    if nl:
+        block_loads(0)
+    for j, (nb, mb) in enumerate(blocks):
+        P = PB + 16 * (j & 1)
+        if nl and j + 1 < len(blocks):
+            block_loads(j + 1)
+        if nl:                                                               # younger than block j's loads: block j-1's two stores, block j+1's loads
+            I(f"s_waitcnt vmcnt({(2 if j else 0) + (nl if j + 1 < len(blocks) else 0)})")
+        elif j == 0:
+            I("s_waitcnt vmcnt(0)")                                          # the bias vectors
+        if mb == 0:
+            for g4 in range(4):                                              # bf16 x4 -> f32 x4: T+24+4 g4 .. +3
+                for d in range(2):
+                    src = BB + 8 * nb + 2 * g4 + d
+                    I(f"v_lshlrev_b32 {vreg(T + 24 + 4 * g4 + 2 * d)}, 16, {vreg(src)}")
+                    I(f"v_and_b32 {vreg(T + 24 + 4 * g4 + 2 * d + 1)}, 0xffff0000, {vreg(src)}")
+        a0 = c.acc(mb, nb)
+        # v = bf16(acc + bias), kept as f32 in T+0..15
+        for r in range(16):
+            I(f"v_accvgpr_read_b32 {vreg(T + r)}, {areg(a0 + r)}")
+        for r in range(0, 16, 2):
+            I(f"v_pk_add_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 24 + r, 2)}")
+        for r in range(0, 16, 2):                                            # round to bf16 and back
+            I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
+        if epi in (EPI_GELU, EPI_GATE_RES):
+            for r in range(0, 16, 2):
+                I(f"v_lshlrev_b32 {vreg(T + r)}, 16, {vreg(T + 16 + r // 2)}")
+                I(f"v_and_b32 {vreg(T + r + 1)}, 0xffff0000, {vreg(T + 16 + r // 2)}")
+        if epi == EPI_GATE_RES:                                              # w = bf16(v * gate[frame][n])
+            for r in range(0, 16, 2):
+                src = P + r // 2
+                I(f"v_lshlrev_b32 {vreg(T + 56)}, 16, {vreg(src)}")
+                I(f"v_and_b32 {vreg(T + 57)}, 0xffff0000, {vreg(src)}")
+                I(f"v_pk_mul_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 56, 2)}")
+            for r in range(0, 16, 2):
+                I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
+        if epi == EPI_GELU:
+            # y = x * rcp(1 + exp2(ce * (k0 * (x + ((k1 * x) * x) * x))))   (gemm_common.h / common.h gelu_tanh, contraction off)
+            for r in range(0, 16, 2):
+                x, t = vreg(T + r, 2), vreg(T + 44 + (r % 4), 2)
+                I(f"v_pk_mul_f32 {t}, {sreg(cons['k1'], 2)}, {x}")
+                I(f"v_pk_mul_f32 {t}, {t}, {x}")
+                I(f"v_pk_mul_f32 {t}, {t}, {x}")
+                I(f"v_pk_add_f32 {t}, {x}, {t}")
+                I(f"v_pk_mul_f32 {t}, {sreg(cons['k0'], 2)}, {t}")
+                I(f"v_pk_mul_f32 {t}, {sreg(cons['ce'], 2)}, {t}")
+                I(f"v_exp_f32 {vreg(T + 44 + (r % 4))}, {vreg(T + 44 + (r % 4))}")
+                I(f"v_exp_f32 {vreg(T + 45 + (r % 4))}, {vreg(T + 45 + (r % 4))}")
+                I("s_nop 0")                                                 # transcendental result -> VALU: one wait state
+                I(f"v_pk_add_f32 {t}, {sreg(cons['one'], 2)}, {t}")
+                I(f"v_rcp_f32 {vreg(T + 44 + (r % 4))}, {vreg(T + 44 + (r % 4))}")
+                I(f"v_rcp_f32 {vreg(T + 45 + (r % 4))}, {vreg(T + 45 + (r % 4))}")
+                I("s_nop 0")
+                I(f"v_pk_mul_f32 {x}, {x}, {t}")
+            for r in range(0, 16, 2):
+                I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
+        # packed bf16 in T+16..23: dwords (2 g4, 2 g4 + 1) = columns 8 g4 + 4 h + (0..3).  T21: swap pairs (g4 = 0,1) and (2,3)
+        for k in (0, 2):
+            ax, ay, bx, by = T + 16 + 2 * k, T + 17 + 2 * k, T + 18 + 2 * k, T + 19 + 2 * k
+            I("s_nop 1")
+            I(f"v_permlane32_swap_b32 {vreg(ax)}, {vreg(bx)}")
+            I(f"v_permlane32_swap_b32 {vreg(ay)}, {vreg(by)}")
+        off_y = 64 * nb
+        if epi in (EPI_GATE_RES, EPI_RES):
+            # residual arithmetic in the 8-column layout after the swap: out = bf16(res + w), w = v or bf16(v * gate)
+            for k in (0, 2):
+                for d in range(4):                                           # 8 columns: res + v in f32, rounded once
+                    vsrc, rsrc = T + 16 + 2 * k + d, P + 8 + 2 * k + d
+                    I(f"v_lshlrev_b32 {vreg(T)}, 16, {vreg(vsrc)}")
+                    I(f"v_and_b32 {vreg(T + 1)}, 0xffff0000, {vreg(vsrc)}")
+                    I(f"v_lshlrev_b32 {vreg(T + 2)}, 16, {vreg(rsrc)}")
+                    I(f"v_and_b32 {vreg(T + 3)}, 0xffff0000, {vreg(rsrc)}")
+                    I(f"v_pk_add_f32 {vreg(T, 2)}, {vreg(T + 2, 2)}, {vreg(T, 2)}")
+                    I(f"v_cvt_pk_bf16_f32 {vreg(vsrc)}, {vreg(T)}, {vreg(T + 1)}")
+        I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
+        for k in (0, 2):
+            I(f"global_store_dwordx4 {vreg(T + 60 + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
+        I("s_mov_b64 exec, -1")
 
 
 if __name__ == "__main__":
