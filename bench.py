@@ -355,7 +355,7 @@ def kernel_table(summary, quant, splitk=False):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
             epi = {"gemm_qkv": 0, "gemm_o": 2, "gemm_cq": 0, "gemm_co": 3, "gemm_f1": 1, "gemm_f2": 2}[tag]      # LL_EPI_* of the call
-            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, 0 if tag == "gemm_qkv" else 1,
+            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, 2 if tag == "gemm_qkv" else 1,
                               1 if (tag == "gemm_f2" and splitk and not i8) else 0)                              # int8: _lin drops split-K
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)

@@ -49,7 +49,7 @@ const char* ll_last_error(void);
  * (default: measured slower at the power limit), 0 = on when it shortens the walk, N = force N workgroups;  "gemm_group_m" = m-tiles per group of the GEMM tile walk
  * (default 4; <= 1: N fastest);  "attn_asm" 1 (default) = the generated one-wave-per-SIMD self-attention kernel
  * (flash_attn_asm_kernel) for >= 1024 keys, 0 = the HIP ping-pong kernel;  "gemm_asm" bit 0 = the generated GEMM kernels
- * (gemm_asm_224_gelu: FFN1; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual) where they cover the call,
+ * (gemm_asm_224_gelu: FFN1; gemm_asm_192_bias: QKV with its V-cache redirect; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual) where they cover the call,
  * bit 1 = also in place of the split-K kernel, bits 2 / 3 = leave the GELU / the 128-wide kernels out (default 3; 0 = HIP
  * kernels only);  "attn_mfma16" 1 = 16x16x32 MFMA variant of the HIP attention kernel (measured slower; A/B only);
  * "gemm_splitk_fault" 1 = test hook: the split-K partner never signals (exercises the bounded wait).
@@ -60,8 +60,8 @@ int ll_set_tuning(const char* key, int value);
 int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap);
 /* The same for a call whose epilogue is known (LL_EPI_*): names the generated one-wave-per-SIMD kernel (gemm_asm_*, tuning key
  * "gemm_asm") where ll_gemm_bf16 (splitk_call = 0) or ll_gemm_bf16_splitk with a workspace (splitk_call = 1) takes it, the
- * split-K kernel where that one runs, else ll_gemm_plan's text.  plain = 1: no V-cache output and no per-batch modulation
- * vector (every block linear of the pipeline except QKV). */
+ * split-K kernel where that one runs, else ll_gemm_plan's text.  plain = 1: an ordinary call (no V-cache output, no per-batch
+ * modulation vector); 2: the fused QKV call (ll_gemm_bf16_qkv, one batch element); 0: a call with a modulation vector. */
 int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int plain, int splitk_call, char* out, int cap);
 int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, int have_workspace, char* out,
                        int cap);

@@ -864,7 +864,7 @@ extern "C" int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int
                                 // bit 1 = ll_gemm_bf16_splitk calls (FFN2) take them too instead of the split-K kernel
 int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
                     int gm, hipStream_t s);
-int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain_epilogue, int frame_len);
+int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool has_v, bool v_ok, int frame_len);
 const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap);
 static bool gemm_asm_wanted(int epilogue) {
   return (g_gemm_asm & 1) && !((g_gemm_asm & 4) && epilogue == LL_EPI_BIAS_GELU) && !((g_gemm_asm & 8) && epilogue != LL_EPI_BIAS_GELU);
@@ -1068,7 +1068,8 @@ extern "C" int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int
   LL_REQUIRE(out != nullptr && cap > 0, "ll_gemm_plan_epi: needs an output buffer");
   const bool sk = splitk_call && splitk_eligible(M, N, int8 ? K : 2 * K);
   if (!int8 && gemm_asm_wanted(epilogue) && (!sk || (g_gemm_asm & 2))) {
-    const int wn = gemm_asm_width(M, N, K, K, epilogue, plain != 0, 1);
+    // plain: 1 = an ordinary call, 0 = per-batch modulation vector (HIP kernels), 2 = the fused QKV call with its V redirect (B = 1)
+    const int wn = gemm_asm_width(M, N, K, K, epilogue, plain != 0, plain == 2, plain == 2 && (2 * (N / 3)) % 192 == 0, 1);
     if (wn) { gemm_asm_plan(M, N, wn, epilogue, out, cap); return LL_OK; }
   }
   if (sk) {

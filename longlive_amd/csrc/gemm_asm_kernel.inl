@@ -3,7 +3,8 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
                                                   const bf16* __restrict__ bias, bf16* __restrict__ Y,
                                                   const bf16* __restrict__ res, const bf16* __restrict__ gate, int M, int N,
                                                   int K, int ldx, int ldo, int frame_len, int gate_stride, int ntm, int ntn,
-                                                  int gm) {
+                                                  int gm, bf16* __restrict__ v_out, int v_col0, int v_C, int v_shift, int v_lo,
+                                                  int v_hi) {
   int mt, nt;
   tile_of(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, gm, mt, nt);
   const int m0 = mt * 256, n0 = nt * (GA_WN);
@@ -13,13 +14,21 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
   unsigned ldx_b = (unsigned)ldx * 2u, ldw_b = (unsigned)K * 2u, ldo_b = (unsigned)ldo * 2u;
   unsigned rows = (unsigned)(M - m0), cols = (unsigned)(N - n0), nk = (unsigned)(K / 64);
   unsigned flen = (unsigned)(frame_len > 0 ? frame_len : 1), gstride = (unsigned)gate_stride, um0 = (unsigned)m0;
-  unsigned tid = threadIdx.x;
+  unsigned tid = threadIdx.x, row_lo = 0;
+  if (v_out != nullptr && n0 >= v_col0) {
+    // a V tile of the fused QKV projection (one batch element): token t -> cache row t + v_shift for v_lo <= t < v_hi (epi_dest)
+    const int hi = (M < v_hi ? M : v_hi) - m0, lo = v_lo > m0 ? v_lo - m0 : 0;
+    if (hi <= lo) return;                                     // nothing of this tile is stored
+    rows = (unsigned)hi; row_lo = (unsigned)lo;
+    yb = (unsigned long long)(v_out + ((long long)m0 + v_shift) * (long long)v_C + (n0 - v_col0));
+    ldo_b = (unsigned)v_C * 2u;
+  }
   asm volatile(
 #include GA_INC
       :
       : "{s[8:9]}"(xb), "{s[10:11]}"(wb), "{s[12:13]}"(yb), "{s[14:15]}"(bb), "{s[16:17]}"(rb), "{s[18:19]}"(gb),
         "{s20}"(ldx_b), "{s21}"(ldw_b), "{s22}"(ldo_b), "{s23}"(rows), "{s24}"(cols), "{s25}"(nk), "{s26}"(flen),
-        "{s27}"(gstride), "{s28}"(um0), "{v0}"(tid)
+        "{s27}"(gstride), "{s28}"(um0), "{s29}"(row_lo), "{v0}"(tid)
       : "memory", "v255", "a255", "s63", "vcc");
   __builtin_unreachable();
 }

@@ -42,6 +42,7 @@ S_X, S_W, S_Y, S_BIAS, S_RES, S_GATE = 8, 10, 12, 14, 16, 18      # 64-bit bases
 S_LDX, S_LDW, S_LDO = 20, 21, 22                                  # row strides in bytes
 S_ROWS, S_COLS, S_NK = 23, 24, 25                                 # valid rows (M - m0), valid columns (N - n0, >= WN on this path), K / 64
 S_FLEN, S_GSTRIDE, S_M0 = 26, 27, 28                              # gate: frame_len (rows per frame), bytes between frames' gate rows, m0
+S_ROWLO = 29                                                      # first row of the tile that is stored (0 except in V tiles of the fused QKV projection)
 # working scalars
 S_XRS, S_WRS = 32, 36                                             # descriptors
 S_WAVE, S_I, S_T0, S_T1, S_T2 = 40, 41, 44, 45, 46
@@ -339,8 +340,10 @@ def gen_epilogue(g: Gen, c: Cfg):
             I(f"v_add_u32 {vreg(q)}, {vreg(q)}, {vreg(t + 2)}")
             I(f"v_mul_lo_u32 {vreg(q)}, {vreg(q)}, {sreg(S_GSTRIDE)}")       # byte offset of the frame's gate row
             I(f"v_lshl_add_u32 {vreg(q)}, {vreg(c.V_H)}, 3, {vreg(q)}")      # + 8 h: the gate is applied in the accumulator layout (as the bias)
-    for mb in range(c.MB):
+    for mb in range(c.MB):                                                   # stored rows: row_lo <= row < rows
         I(f"v_cmp_lt_u32_e64 {sreg(S_MSK + 2 * mb, 2)}, {vreg(c.V_ROW + mb)}, {sreg(S_ROWS)}")
+        I(f"v_cmp_ge_u32_e64 vcc, {vreg(c.V_ROW + mb)}, {sreg(S_ROWLO)}")
+        I(f"s_and_b64 {sreg(S_MSK + 2 * mb, 2)}, {sreg(S_MSK + 2 * mb, 2)}, vcc")
     # Every global read of the epilogue is issued ahead of its use (one exposed latency per kernel, not one per block): all bias
     # vectors first, then the gate / residual pieces of block j + 1 while block j computes (two buffers of 16 registers).
     BB, PB = T + 72, T + 72 + 8 * c.NB                                       # bias raw [nb][g4] (2 registers each); block buffers P[2][16]

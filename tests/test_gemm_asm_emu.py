@@ -28,7 +28,7 @@ def rbf(x):
     return f32(bf(x))
 
 
-def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130):
+def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130, row_lo=0):
     rng = np.random.default_rng(seed)
     text = G.generate(WN, epi, f"T{WN}E{epi}")
     assert G.lint(text) == []
@@ -51,6 +51,7 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
         s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K * 2, K * 2, N * 2
         s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 64
         s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
+        s[G.S_ROWLO] = row_lo
         wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
         wv.v[1:] = 0x7FC0BEEF
         wv.a[:] = 0x7FC0BEEF
@@ -101,6 +102,14 @@ def test_gemm_asm_widest_tile_fills_the_lds():
     assert G.Cfg(256, G.EPI_RES).lds_bytes == 160 * 1024
     got, want = run_case(256, G.EPI_RES, "lazy", rows_valid=130, K=512)
     assert (got == want).mean() > 0.97 and np.abs(got - want).max() < 0.05
+
+
+def test_gemm_asm_qkv_tile_stores_only_its_row_window():
+    """The 192-wide kernel of the fused QKV projection: a V tile stores rows row_lo <= row < rows only (tokens outside the cache
+    insert window are not written: gemm_common.h epi_dest)."""
+    got, want = run_case(192, G.EPI_BIAS, "lazy", rows_valid=150, K=320, row_lo=37)
+    assert np.isnan(got[:37]).all(), "rows below the window were written"
+    assert (got[37:] == want[37:]).mean() > 0.97 and np.abs(got[37:] - want[37:]).max() < 0.05
 
 
 def test_gemm_asm_text_assembles(tmp_path):
