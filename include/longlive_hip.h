@@ -48,7 +48,7 @@ const char* ll_last_error(void);
  * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on;  "attn_sk_wgs" -1 = stream-K attention off
  * (default: measured slower at the power limit), 0 = on when it shortens the walk, N = force N workgroups;  "gemm_group_m" = m-tiles per group of the GEMM tile walk
  * (default 4; <= 1: N fastest);  "attn_asm" 1 (default) = the generated one-wave-per-SIMD self-attention kernel
- * (flash_attn_asm_kernel) for >= 1024 keys, 0 = the HIP ping-pong kernel;  "gemm_asm" bit 0 = the generated GEMM kernels
+ * (flash_attn_asm_kernel) for single key ranges of >= "attn_asm_min_keys" keys (default 512: self- and cross-attention), 0 = the HIP kernels;  "gemm_asm" bit 0 = the generated GEMM kernels
  * (gemm_asm_224_gelu: FFN1; gemm_asm_192_bias: QKV with its V-cache redirect; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual) where they cover the call,
  * bit 1 = also in place of the split-K kernel, bits 2 / 3 = leave the GELU / the 128-wide kernels out (default 3; 0 = HIP
  * kernels only);  "attn_mfma16" 1 = 16x16x32 MFMA variant of the HIP attention kernel (measured slower; A/B only);

@@ -1220,8 +1220,10 @@ static int g_attn_asm = 1;        // tuning key attn_asm (DEFAULT 1; 0 = flash_a
 void ll_set_attn_asm_internal(int v) { g_attn_asm = v; }
 int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk,
                           long long k_batch_stride, int kstart, int nkeys, float c, int xcd, int form, hipStream_t stream);
+static int g_attn_asm_min_keys = 8 * KT;    // the generated kernel from 512 keys on (cross-attention: 22.7 vs 26.8 us, profiles/r03_cross_attn_asm.txt)
+void ll_set_attn_asm_min_internal(int v) { g_attn_asm_min_keys = v; }
 static bool attn_asm_eligible(int nkeys, int ldk) {
-  return g_attn_asm && g_attn_variant >= 2 && nkeys >= g_attn_pp_min_keys && (long long)nkeys * ldk * 2 < 0x7fffffffLL;
+  return g_attn_asm && g_attn_variant >= 2 && nkeys >= g_attn_asm_min_keys && (long long)nkeys * ldk * 2 < 0x7fffffffLL;
 }
 static int g_attn_mfma16 = 0;     // tuning key attn_mfma16: 1 = the ping-pong loop on v_mfma_f32_16x16x32_bf16 (flash_attn_pipe16_kernel)
 void ll_set_attn_mfma16_internal(int v) { g_attn_mfma16 = v; }

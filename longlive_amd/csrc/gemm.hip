@@ -703,6 +703,7 @@ void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
 void ll_set_attn_sk_internal(int v);
 void ll_set_attn_pp_min_internal(int v);
+void ll_set_attn_asm_min_internal(int v);
 void ll_set_attn_mfma16_internal(int v);
 void ll_set_attn_asm_internal(int v);
 void ll_set_conv_halo_internal(int v);
@@ -726,6 +727,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "attn_xcd")) { ll_set_attn_xcd_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_sk_wgs")) { ll_set_attn_sk_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_pp_min_keys")) { ll_set_attn_pp_min_internal(value); return LL_OK; }
+  if (!strcmp(key, "attn_asm_min_keys")) { ll_set_attn_asm_min_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_mfma16")) { ll_set_attn_mfma16_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_asm")) { ll_set_attn_asm_internal(value); return LL_OK; }
   if (!strcmp(key, "conv_halo")) { ll_set_conv_halo_internal(value); return LL_OK; }
