@@ -81,6 +81,16 @@ class Cfg:
         self.V_LANE, self.V_R, self.V_H, self.V_ROW = nxt + 32, nxt + 33, nxt + 34, nxt + 35      # V_ROW[mb] -> +35, +36
         self.V_T = 0                                              # epilogue temporaries re-use the fragment file
         assert nxt + 37 <= 256, nxt
+        # registers above the loop's own: epilogue addresses (computed before the loop) and the epilogue's EARLY reads -- bias
+        # vectors of the first `early_nb` column blocks and the first block's gate / residual pieces are fetched before the
+        # first staging piece, so the epilogue starts without an exposed memory latency
+        self.V_EA = nxt + 37                                      # +0,+1 row byte offsets in Y / RES; +2 bias column offset; +3,+4 gate row offsets
+        top = self.V_EA + 5
+        self.nl = {EPI_GATE_RES: 6, EPI_RES: 2}.get(epi, 0)       # global reads per epilogue block
+        self.V_E0 = top                                           # the first block's gate / residual pieces (16 registers) when nl
+        top += 16 if self.nl else 0
+        self.V_EB = top                                           # early bias [nb][g4], 2 registers each
+        self.early_nb = max(0, min(self.NB, (256 - top) // 8))
 
     def acc(self, mb, nb):
         return (mb * self.NB + nb) * 16
@@ -221,6 +231,7 @@ def generate(WN: int, epi: int, prefix: str) -> str:
     # prologue staging in the loop's own issue order: W(0) X(0) W(1) X(1) W(2)
     I(f"s_cmp_ge_u32 {sreg(S_T0)}, {sreg(S_ROWS)}")                        # idle waves (their 64 rows are all past M) stage W only
     I(f"s_cbranch_scc1 {prefix}_IDLE")
+    gen_epilogue_setup(g, c)                           # addresses, masks and the early reads of the epilogue (oldest in the queue)
     for j in range(NSLOT):
         for op in w_dma(c, j):
             I(op)
@@ -297,30 +308,23 @@ def generate(WN: int, epi: int, prefix: str) -> str:
 
 
 
-def gen_epilogue(g: Gen, c: Cfg):
-    """per (mb, nb): 16 accumulators of a lane = its row m, columns 32 nb + 8 g4 + 4 h + (0..3), g4 = 0..3"""
+def gen_epilogue_setup(g: Gen, c: Cfg):
+    """Before the loop (active waves): the epilogue's addresses and masks, and its early reads (the OLDEST entries of the wave's
+    vmcnt queue: every later wait covers them)."""
     I = g.I
     T = c.V_T
     epi = c.epi
-    K0, K1, CEXP = 0.7978845608028654, 0.044715, -2.0 * 1.4426950408889634
-    # constants in SGPR pairs for the packed ops
-    cons = {}
-    def const_pair(name, val, s0):
-        I(f"s_mov_b32 {sreg(s0)}, {hex(f32bits(val))}")
-        I(f"s_mov_b32 {sreg(s0 + 1)}, {hex(f32bits(val))}")
-        cons[name] = s0
-    if epi == EPI_GELU:
-        const_pair("k1", K1, 54); const_pair("k0", K0, 56); const_pair("ce", CEXP, 58); const_pair("one", 1.0, 60)
-    # row addressing: byte offset of the lane's row in Y / RES: row * ldo + 16 h (the swap gives the upper half the second 16 bytes... see below)
+    EA = c.V_EA
+    # row addressing: byte offset of the lane's row in Y / RES: row * ldo + 16 h (the swap gives the upper half the second 16 bytes)
     for mb in range(c.MB):
-        I(f"v_mul_lo_u32 {vreg(T + 60 + mb)}, {vreg(c.V_ROW + mb)}, {sreg(S_LDO)}")
-        I(f"v_lshl_add_u32 {vreg(T + 60 + mb)}, {vreg(c.V_H)}, 4, {vreg(T + 60 + mb)}")
-    I(f"v_lshlrev_b32 {vreg(T + 62)}, 3, {vreg(c.V_H)}")                     # bias / gate column byte offset of this half: 8 h
+        I(f"v_mul_lo_u32 {vreg(EA + mb)}, {vreg(c.V_ROW + mb)}, {sreg(S_LDO)}")
+        I(f"v_lshl_add_u32 {vreg(EA + mb)}, {vreg(c.V_H)}, 4, {vreg(EA + mb)}")
+    I(f"v_lshlrev_b32 {vreg(EA + 2)}, 3, {vreg(c.V_H)}")                     # bias / gate column byte offset of this half: 8 h
     if epi == EPI_GATE_RES:
         # gate row of the lane's row: frame = (m0 + row) / frame_len  (integer division via float with one correction each way)
         I(f"s_sub_u32 {sreg(S_T1)}, {sreg(S_ROWS)}, 1")                      # rows past M take the last valid row's frame (gemm_common.h: mc = min(m, M - 1)):
         for mb in range(c.MB):                                               # their gate address must stay inside the table
-            m, q, t = T + 66, T + 64 + mb, T + 48
+            m, q, t = T + 66, EA + 3 + mb, T + 48
             I(f"v_min_u32 {vreg(m)}, {sreg(S_T1)}, {vreg(c.V_ROW + mb)}")
             I(f"v_add_u32 {vreg(m)}, {sreg(S_M0)}, {vreg(m)}")
             I(f"v_cvt_f32_u32 {vreg(t)}, {vreg(m)}")
@@ -344,42 +348,72 @@ def gen_epilogue(g: Gen, c: Cfg):
         I(f"v_cmp_lt_u32_e64 {sreg(S_MSK + 2 * mb, 2)}, {vreg(c.V_ROW + mb)}, {sreg(S_ROWS)}")
         I(f"v_cmp_ge_u32_e64 vcc, {vreg(c.V_ROW + mb)}, {sreg(S_ROWLO)}")
         I(f"s_and_b64 {sreg(S_MSK + 2 * mb, 2)}, {sreg(S_MSK + 2 * mb, 2)}, vcc")
-    # Every global read of the epilogue is issued ahead of its use (one exposed latency per kernel, not one per block): all bias
-    # vectors first, then the gate / residual pieces of block j + 1 while block j computes (two buffers of 16 registers).
-    BB, PB = T + 72, T + 72 + 8 * c.NB                                       # bias raw [nb][g4] (2 registers each); block buffers P[2][16]
-    assert PB + 32 <= min(c.V_WOFF + 32, 256), (PB, c.V_WOFF)               # below the registers that survive the loop (V_LANE ...)
-    for nb in range(c.NB):                                                   # lane needs columns 32 nb + 8 g4 + 4 h + (0..3): 4 loads of 8 bytes
+    # early reads
+    for nb in range(c.early_nb):
         for g4 in range(4):
-            I(f"global_load_dwordx2 {vreg(BB + 8 * nb + 2 * g4, 2)}, {vreg(T + 62)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
+            I(f"global_load_dwordx2 {vreg(c.V_EB + 8 * nb + 2 * g4, 2)}, {vreg(EA + 2)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
+    if c.nl:
+        epi_block_loads(g, c, 0, c.V_E0)
+
+
+def epi_block_loads(g: Gen, c: Cfg, j: int, P: int):
+    """gate / residual pieces of epilogue block j = (nb, mb) into P[0:16]"""
+    I = g.I
+    nb, mb = j // c.MB, j % c.MB
+    EA = c.V_EA
+    if c.epi == EPI_GATE_RES:                                                # gate[frame][n] in the accumulator layout (as the bias)
+        for g4 in range(4):
+            I(f"global_load_dwordx2 {vreg(P + 2 * g4, 2)}, {vreg(EA + 3 + mb)}, {sreg(S_GATE, 2)} offset:{64 * nb + 16 * g4}")
+    if c.epi in (EPI_GATE_RES, EPI_RES):                                     # residual in the 8-column layout after the swap
+        I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
+        for k in (0, 2):
+            I(f"global_load_dwordx4 {vreg(P + 8 + 2 * k, 4)}, {vreg(EA + mb)}, {sreg(S_RES, 2)} offset:{64 * nb + 16 * k}")
+        I("s_mov_b64 exec, -1")
+
+
+def gen_epilogue(g: Gen, c: Cfg):
+    """per (mb, nb): 16 accumulators of a lane = its row m, columns 32 nb + 8 g4 + 4 h + (0..3), g4 = 0..3"""
+    I = g.I
+    T = c.V_T
+    epi = c.epi
+    EA = c.V_EA
+    K0, K1, CEXP = 0.7978845608028654, 0.044715, -2.0 * 1.4426950408889634
+    # constants in SGPR pairs for the packed ops
+    cons = {}
+    def const_pair(name, val, s0):
+        I(f"s_mov_b32 {sreg(s0)}, {hex(f32bits(val))}")
+        I(f"s_mov_b32 {sreg(s0 + 1)}, {hex(f32bits(val))}")
+        cons[name] = s0
+    if epi == EPI_GELU:
+        const_pair("k1", K1, 54); const_pair("k0", K0, 56); const_pair("ce", CEXP, 58); const_pair("one", 1.0, 60)
+    # Every global read of the epilogue is issued ahead of its use: the early ones before the loop (gen_epilogue_setup), here the
+    # bias vectors that did not fit up there, then the gate / residual pieces of block j + 1 while block j computes.
+    BB, PB = T + 72, T + 72 + 8 * c.NB                                       # late bias raw [nb][g4] (2 registers each); block buffers P[2][16]
+    assert PB + 32 <= min(c.V_WOFF + 32, 256), (PB, c.V_WOFF)               # below the registers that survive the loop (V_LANE ...)
+    n_late = 4 * (c.NB - c.early_nb)
+    for nb in range(c.early_nb, c.NB):                                       # lane needs columns 32 nb + 8 g4 + 4 h + (0..3): 4 loads of 8 bytes
+        for g4 in range(4):
+            I(f"global_load_dwordx2 {vreg(BB + 8 * nb + 2 * g4, 2)}, {vreg(EA + 2)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
     blocks = [(nb, mb) for nb in range(c.NB) for mb in range(c.MB)]
-    nl = {EPI_GATE_RES: 6, EPI_RES: 2}.get(epi, 0)                           # loads per block
+    nl = c.nl
 
-    def block_loads(j):
-        nb, mb = blocks[j]
-        P = PB + 16 * (j & 1)
-        if epi == EPI_GATE_RES:                                              # gate[frame][n] in the accumulator layout (as the bias)
-            for g4 in range(4):
-                I(f"global_load_dwordx2 {vreg(P + 2 * g4, 2)}, {vreg(T + 64 + mb)}, {sreg(S_GATE, 2)} offset:{64 * nb + 16 * g4}")
-        if epi in (EPI_GATE_RES, EPI_RES):                                   # residual in the 8-column layout after the swap
-            I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
-            for k in (0, 2):
-                I(f"global_load_dwordx4 {vreg(P + 8 + 2 * k, 4)}, {vreg(T + 60 + mb)}, {sreg(S_RES, 2)} offset:{64 * nb + 16 * k}")
-            I("s_mov_b64 exec, -1")
-
-    if nl:
-        block_loads(0)
     for j, (nb, mb) in enumerate(blocks):
-        P = PB + 16 * (j & 1)
+        P = c.V_E0 if j == 0 else PB + 16 * (j & 1)
         if nl and j + 1 < len(blocks):
-            block_loads(j + 1)
-        if nl:                                                               # younger than block j's loads: block j-1's two stores, block j+1's loads
-            I(f"s_waitcnt vmcnt({(2 if j else 0) + (nl if j + 1 < len(blocks) else 0)})")
-        elif j == 0:
+            epi_block_loads(g, c, j + 1, PB + 16 * ((j + 1) & 1))
+        nxt_loads = nl if (nl and j + 1 < len(blocks)) else 0
+        if nl and j == 0:
+            I(f"s_waitcnt vmcnt({(n_late if c.early_nb else 0) + nxt_loads})")   # block 0's pieces are early; its bias vector is late only when none fit up there
+        elif nl:                                                             # younger than block j's loads: block j-1's two stores, block j+1's loads
+            I(f"s_waitcnt vmcnt({2 + nxt_loads})")
+        elif c.early_nb == 0 and j == 0:
             I("s_waitcnt vmcnt(0)")                                          # the bias vectors
+        if not nl and mb == 0 and nb == c.early_nb and 0 < c.early_nb < c.NB:
+            I(f"s_waitcnt vmcnt({min(63, 2 * j)})")                          # the late bias vectors (younger: the stores so far)
         if mb == 0:
             for g4 in range(4):                                              # bf16 x4 -> f32 x4: T+24+4 g4 .. +3
                 for d in range(2):
-                    src = BB + 8 * nb + 2 * g4 + d
+                    src = (c.V_EB if nb < c.early_nb else BB) + 8 * nb + 2 * g4 + d
                     I(f"v_lshlrev_b32 {vreg(T + 24 + 4 * g4 + 2 * d)}, 16, {vreg(src)}")
                     I(f"v_and_b32 {vreg(T + 24 + 4 * g4 + 2 * d + 1)}, 0xffff0000, {vreg(src)}")
         a0 = c.acc(mb, nb)
@@ -442,7 +476,7 @@ def gen_epilogue(g: Gen, c: Cfg):
                     I(f"v_cvt_pk_bf16_f32 {vreg(vsrc)}, {vreg(T)}, {vreg(T + 1)}")
         I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
         for k in (0, 2):
-            I(f"global_store_dwordx4 {vreg(T + 60 + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
+            I(f"global_store_dwordx4 {vreg(EA + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
         I("s_mov_b64 exec, -1")
 
 
