@@ -32,6 +32,17 @@ def short(name):
     return name
 
 
+def label(name, us):
+    """one kernel name, two launch shapes per layer: told apart by the dispatch's own duration"""
+    if us is None:
+        return name
+    if "flash_attn_asm_kernel" in name:
+        return name + (" [self, Lk=18720]" if us > 100 else " [cross, Lk=512]")
+    if "gemm_asm_128_gate_res" in name:
+        return name + (" [FFN2, K=8960]" if us > 60 else " [O, K=1536]")
+    return name
+
+
 def load_counters(d):
     files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
     if not files:
@@ -44,6 +55,8 @@ def load_counters(d):
         per[i][r["Counter_Name"]] = per[i].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         if r.get("End_Timestamp") and r.get("Start_Timestamp"):       # the counted run's own duration of this dispatch
             per[i]["_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    for i in meta:
+        meta[i] = label(meta[i], per[i].get("_us"))
     return per, meta
 
 
@@ -70,7 +83,8 @@ def load_trace(d):
     rows = rows[len(rows) - len(rows) // 3:]
     acc = defaultdict(list)
     for r in rows:
-        acc[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        acc[label(short(r["Kernel_Name"]), us)].append(us)
     span = (max(int(r["End_Timestamp"]) for r in rows) - min(int(r["Start_Timestamp"]) for r in rows)) * 1e-6
     return {g: (sum(v) / len(v), len(v)) for g, v in acc.items()}, span
 
@@ -127,7 +141,7 @@ def main():
         f = lambda x, fmt: "-" if x is None else fmt % x
         share = None if not (us and total_us) else us * n / total_us
         lines.append("| `%s` | %d | %s | %s | %s | %s | %s | %s | %s |" % (
-            g[:70], n, f(us, "%.1f"), f(share and 100 * share, "%.1f %%"), f(d.get("mfma_util") and 100 * d["mfma_util"], "%.1f %%"),
+            g[:96], n, f(us, "%.1f"), f(share and 100 * share, "%.1f %%"), f(d.get("mfma_util") and 100 * d["mfma_util"], "%.1f %%"),
             f(d.get("busy_cycles_per_mfma"), "%.1f"), f(d.get("implied_clock_ghz"), "%.2f"),
             "-" if "SQ_WAIT_ANY_share" not in d else "%.0f / %.0f / %.0f %%" % (100 * d["SQ_WAIT_ANY_share"], 100 * d["SQ_WAIT_INST_ANY_share"], 100 * d["SQ_ACTIVE_INST_ANY_share"]),
             f(d.get("fabric_bytes_per_launch") and d["fabric_bytes_per_launch"] / 1e6, "%.1f")))
