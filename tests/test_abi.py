@@ -88,6 +88,38 @@ def test_splitk_workspace_size_and_plan_without_a_gpu():
         assert lib.ll_gemm_splitk_plan(4680, 1536, 8960, 0) == 0
 
 
+def test_gemm_plan_names_the_kernel_family_a_call_takes():
+    """ll_gemm_plan_epi (host only): under the shipped tuning the six block linears of the pipeline take the generated kernels
+    (gemm_asm_<width>_<epilogue>), int8 / modulation-vector calls and unsupported widths the HIP ones; tuning key gemm_asm = 0
+    restores the HIP set; unknown tuning keys are rejected."""
+    import ctypes as C
+    lib = _lib.load()
+    buf = C.create_string_buffer(256)
+
+    def plan(M, N, K, i8, epi, plain, sk=0):
+        _lib.check(lib.ll_gemm_plan_epi(M, N, K, i8, epi, plain, sk, buf, 256), "plan")
+        return buf.value.decode()
+
+    L, Cw, F1 = 4680, 1536, 8960
+    assert plan(L, F1, Cw, 0, 1, 1).startswith("gemm_asm_224_gelu")
+    assert plan(L, 3 * Cw, Cw, 0, 0, 2).startswith("gemm_asm_192_bias")            # fused QKV, one batch element
+    assert plan(L, Cw, Cw, 0, 2, 1).startswith("gemm_asm_128_gate_res")
+    assert plan(L, Cw, Cw, 0, 3, 1).startswith("gemm_asm_128_res")
+    assert plan(L, Cw, Cw, 0, 0, 1).startswith("gemm_asm_128_bias")
+    assert "760 workgroups" in plan(L, F1, Cw, 0, 1, 1) and "456 workgroups" in plan(L, 3 * Cw, Cw, 0, 0, 2)
+    for text in (plan(L, Cw, Cw, 1, 2, 1), plan(L, Cw, Cw, 0, 2, 0), plan(L, 1000, Cw, 0, 0, 1), plan(L, F1, 192, 0, 1, 1)):
+        assert text.startswith("gemm_kernel_v"), text                                # int8; modulation vector; N % 128; K < 256
+    assert lib.ll_gemm_plan_epi(L, Cw, Cw, 0, 0, 1, 0, None, 0) == -1
+    try:
+        assert lib.ll_set_tuning(b"gemm_asm", 0) == 0
+        assert plan(L, F1, Cw, 0, 1, 1).startswith("gemm_kernel_v5")
+    finally:
+        assert lib.ll_set_tuning(b"gemm_asm", 3) == 0
+    for key in (b"attn_asm", b"attn_asm_min_keys", b"gemm_asm", b"attn_mfma16", b"gemm_splitk_fault"):
+        assert lib.ll_set_tuning(key, {b"attn_asm": 1, b"attn_asm_min_keys": 512, b"gemm_asm": 3}.get(key, 0)) == 0, key
+    assert lib.ll_set_tuning(b"no_such_key", 1) == -1
+
+
 def test_ops_refuse_cpu_tensors():
     """No CPU fallback: handing the product path a host tensor is an error, not a silent slow path."""
     import torch
