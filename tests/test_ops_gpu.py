@@ -312,6 +312,8 @@ def test_flash_attn_mfma16_variant_rescale(ops):
     (1, 257, 2, 2000, (37, 1100)),        # key range that does not start at slot 0 and ENDS before the tensor does
     (1, 520, 12, 1300, (0, 1300)),        # real head count, 3 q-tiles; the key range ends exactly at the end of the tensor
     (1, 72, 2, 1081, (0, 1081)),          # last tile holds 57 keys; 72 rows = the last q-tile of Lq 4680
+    (2, 300, 12, 512, (0, 512)),          # cross-attention's range: exactly attn_asm_min_keys (8 tiles), batch 2
+    (1, 130, 2, 700, (64, 633)),          # 569 keys: 9 tiles, the last one with 57 keys; shorter than the loop's unroll + prologue
 ])
 def test_flash_attn_asm_kernel(ops, form, B, Lq, H, Sk, seg):
     """flash_attn_asm_kernel (tuning key attn_asm): the generated one-wave-per-SIMD kernel against fp64 and against the shipped kernel."""
