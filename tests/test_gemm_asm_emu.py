@@ -112,6 +112,15 @@ def test_gemm_asm_qkv_tile_stores_only_its_row_window():
     assert (got[37:] == want[37:]).mean() > 0.97 and np.abs(got[37:] - want[37:]).max() < 0.05
 
 
+@pytest.mark.parametrize("rows_valid,K", [(1, 256), (65, 256), (256, 320)])
+def test_gemm_asm_shortest_k_and_single_row(rows_valid, K):
+    """K = 256 is the shortest the launcher sends here (4 K-steps: fewer than the loop's unroll, the prologue stages past the end
+    and re-loads the last step); one valid row leaves three idle waves and 63 masked lanes."""
+    got, want = run_case(128, G.EPI_GATE_RES, "lazy", rows_valid=rows_valid, K=K, m0=0, frame_len=40)
+    assert np.isfinite(got).all()
+    assert (got == want).mean() > 0.95 and np.abs(got - want).max() < 0.07
+
+
 def test_gemm_asm_text_assembles(tmp_path):
     clang = "/opt/rocm/lib/llvm/bin/clang"
     if not os.path.exists(clang):
