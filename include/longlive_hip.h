@@ -151,6 +151,18 @@ int ll_gemm_w8a8_splitk(const int8_t* xq, const float* sx, const int8_t* wq, con
                         int nmod, int gate_idx, int rows_per_batch, int frame_len, void* workspace, long long workspace_bytes,
                         ll_stream stream);
 
+/* Small-M form of ll_gemm_bf16 for the 512-token linears of the text side (umT5 self-attention / FFN projections,
+ * wan/modules/t5.py:65-117,134-160; the text K/V projections of cross-attention, wan/modules/model.py:183-188): a grid of
+ * ceil(M / 256) x (N / 128) tiles fills a fraction of the device, so K is cut into ll_gemm_ksplit_plan(M, N, K) ranges (0 = not
+ * taken for this shape on this device), each range's fp32 tile sums go to `workspace` ([splits][M][N] floats, caller-owned, at
+ * least ll_gemm_ksplit_workspace_bytes bytes, 16-byte aligned, no initialisation needed) and one pass adds them in a fixed order
+ * and applies the epilogue (LL_EPI_BIAS or LL_EPI_BIAS_RES).  Results equal ll_gemm_bf16's up to the order of the fp32 sum;
+ * bit-identical run to run.  workspace = NULL or plan = 0: it IS ll_gemm_bf16. */
+int ll_gemm_ksplit_plan(int M, int N, int K);
+long long ll_gemm_ksplit_workspace_bytes(int M, int N, int K);
+int ll_gemm_bf16_ksplit(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
+                        int ldo, int epilogue, const ll_bf16* res, void* workspace, long long workspace_bytes, ll_stream stream);
+
 /* W8A8 variant of ll_gemm_bf16 for BASELINE config 5 ("INT8-quantized linear layers"; the reference ships no INT8 code,
  * reports.md:24,39): out = epilogue(sx[m] * sw[n] * (xq[M,K] . wq[N,K]^T) + bias) with int8 operands, exact int32
  * accumulation on v_mfma_i32_16x16x64_i8 and the same fused epilogues.  sx [M] / sw [N] fp32; K % 128 == 0. */

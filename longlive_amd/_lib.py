@@ -34,6 +34,9 @@ SIGNATURES = {
     "ll_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
     "ll_gemm_splitk_workspace_bytes": [_i, _i],
     "ll_gemm_splitk_plan": [_i, _i, _i, _i],
+    "ll_gemm_ksplit_plan": [_i, _i, _i],
+    "ll_gemm_ksplit_workspace_bytes": [_i, _i, _i],
+    "ll_gemm_bf16_ksplit": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _ll, _p],
     "ll_gemm_splitk_status": [_p, _p, _p],
     "ll_gemm_w8a8_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -58,7 +61,7 @@ SIGNATURES = {
     "ll_t5_attention": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
 _RESTYPES = {"ll_last_error": C.c_char_p, "ll_flash_attn_workspace_bytes": C.c_longlong,
-             "ll_gemm_splitk_workspace_bytes": C.c_longlong}
+             "ll_gemm_splitk_workspace_bytes": C.c_longlong, "ll_gemm_ksplit_workspace_bytes": C.c_longlong}
 
 _lib = None
 

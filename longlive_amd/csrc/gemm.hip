@@ -867,6 +867,9 @@ extern "C" int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int
 int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
                     int gm, hipStream_t s);
 int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool has_v, bool v_ok, int frame_len);
+int gemm_ksplit_splits(int M, int N, int K, int cus);
+int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, int M, int N, int K, int ldx, int ldo,
+                           int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s);
 const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap);
 static bool gemm_asm_wanted(int epilogue) {
   return (g_gemm_asm & 1) && !((g_gemm_asm & 4) && epilogue == LL_EPI_BIAS_GELU) && !((g_gemm_asm & 8) && epilogue != LL_EPI_BIAS_GELU);
@@ -996,6 +999,40 @@ extern "C" int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b
              rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
   launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream);
   return ll_check_launch("ll_gemm_bf16");
+}
+
+// Small-M split-K (gemm_asm.hip): how many K-ranges the call would be cut into on this device (0 = the path is not taken: the
+// shape already fills half the device, N % 128, K too short, no device, or the generated kernels are switched off).
+static int device_cus();
+extern "C" int ll_gemm_ksplit_plan(int M, int N, int K) {
+  if (!(g_gemm_asm & 1)) return 0;
+  return gemm_ksplit_splits(M, N, K, device_cus());
+}
+extern "C" long long ll_gemm_ksplit_workspace_bytes(int M, int N, int K) {
+  const int S = ll_gemm_ksplit_plan(M, N, K);
+  return S ? (long long)S * M * N * 4 : 0;
+}
+extern "C" int ll_gemm_bf16_ksplit(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K,
+                                   int ldx, int ldo, int epilogue, const ll_bf16* res, void* workspace,
+                                   long long workspace_bytes, ll_stream stream) {
+  LL_REQUIRE(K > 0 && K % 64 == 0, "ll_gemm_bf16_ksplit: K=%d must be a positive multiple of 64", K);
+  LL_REQUIRE(ldx >= K && ldx % 8 == 0, "ll_gemm_bf16_ksplit: ldx=%d must be >= K and a multiple of 8", ldx);
+  LL_REQUIRE(epilogue == LL_EPI_BIAS || epilogue == LL_EPI_BIAS_RES, "ll_gemm_bf16_ksplit: epilogue %d (bias or bias + residual only)", epilogue);
+  int rc = check_epilogue("ll_gemm_bf16_ksplit", M, N, ldo, epilogue, bias, res, nullptr, nullptr, 0, 0, 0, 0);
+  if (rc) return rc;
+  LL_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "ll_gemm_bf16_ksplit: workspace_bytes without a workspace");
+  if (M == 0) return LL_OK;
+  const int S = ll_gemm_ksplit_plan(M, N, K);
+  if (S >= 2 && workspace != nullptr && ldo % 8 == 0) {
+    LL_REQUIRE(workspace_bytes >= (long long)S * M * N * 4 && ((size_t)workspace & 15) == 0,
+               "ll_gemm_bf16_ksplit: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes, (long long)S * M * N * 4);
+    if (gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, epilogue,
+                               (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream))
+      return ll_check_launch("ll_gemm_bf16_ksplit");
+  }
+  EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+  launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream);
+  return ll_check_launch("ll_gemm_bf16_ksplit");
 }
 
 // Split-K form of ll_gemm_bf16 (gemm_kernel_v4sk): same arguments plus a workspace.  Taken when N is a multiple of 256, K a

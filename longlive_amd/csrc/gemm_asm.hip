@@ -40,6 +40,16 @@
 #undef GA_WN
 #undef GA_INC
 
+#define GA_NAME gemm_asm_128_partial
+#define GA_WN 128
+#define GA_INC "build/gemm_asm_128_4.inc"
+#define GA_PARTIAL 1
+#include "gemm_asm_kernel.inl"
+#undef GA_PARTIAL
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+
 // tile width of the generated kernel that covers this call, 0 = none (the caller takes the HIP kernels).
 // plain = no int8 scales, no per-batch modulation vector; v_ok = no V-cache output, or one the 192-wide kernel can redirect per
 // tile (one batch element, the V third starting on a tile boundary)
@@ -50,7 +60,8 @@ int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool 
   if (has_v) return (v_ok && epilogue == LL_EPI_BIAS && N % 192 == 0) ? 192 : 0;
   if (epilogue == LL_EPI_BIAS_GELU) return N % 224 == 0 ? 224 : 0;
   if (epilogue == LL_EPI_BIAS && N > 2048 && N % 192 == 0) return 192;
-  if (N % 128 == 0 && N <= 2048 && (epilogue == LL_EPI_BIAS || epilogue == LL_EPI_BIAS_GATE_RES || epilogue == LL_EPI_BIAS_RES)) return 128;
+  if (N % 128 == 0 && (N <= 2048 || M <= 1024) &&      // wide outputs of few rows (umT5's gated FFN, 512 x 20480): the HIP choice there is 256 x 128 as well
+      (epilogue == LL_EPI_BIAS || epilogue == LL_EPI_BIAS_GATE_RES || epilogue == LL_EPI_BIAS_RES)) return 128;
   return 0;
 }
 
@@ -87,4 +98,75 @@ const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap
   snprintf(out, (size_t)cap, "gemm_asm_%d_%s<bf16> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", wn,
            tail, wn, ((M + 255) / 256) * (N / wn));
   return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small-M split-K (umT5's linears at 512 tokens, wan/modules/t5.py:65-117; the text K/V projections): a grid of
+// ceil(M / 256) x (N / 128) tiles fills a quarter of the device, so K is cut into `splits` ranges -- each workgroup of
+// gemm_asm_128_partial writes its tile's fp32 accumulators to workspace[split][M][N], and one elementwise pass sums the ranges in
+// a fixed order and applies the epilogue (bias, or bias + residual) with gemm_common.h's rounding points.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                                                 const bf16* __restrict__ bias, const bf16* __restrict__ res,
+                                                                 bf16* __restrict__ out, int ldo) {
+  const int n8 = N / 8;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)M * n8) return;
+  const int m = (int)(idx / n8), n = (int)(idx - (long long)m * n8) * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int s = 0; s < splits; ++s) {                  // fixed order: bit-identical run to run
+    const float4* p = reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * N + n);
+    float4 a = p[0], b = p[1];
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+  }
+  bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + n), o;
+  bf16x8 rv;
+  if (EPI == LL_EPI_BIAS_RES) rv = *reinterpret_cast<const bf16x8*>(res + (size_t)m * ldo + n);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bf16 v = (bf16)(acc[j] + (float)bv[j]);
+    o[j] = EPI == LL_EPI_BIAS_RES ? (bf16)((float)rv[j] + (float)v) : v;
+  }
+  *reinterpret_cast<bf16x8*>(out + (size_t)m * ldo + n) = o;
+}
+
+// splits the small-M path would use for this shape on a device of `cus` compute units; 0 = not taken
+int gemm_ksplit_splits(int M, int N, int K, int cus) {
+  if (M <= 0 || N <= 0 || N % 128 != 0 || K % 64 != 0 || K < 1024 || cus <= 0) return 0;
+  const long long tiles = (long long)((M + 255) / 256) * (N / 128);
+  if (tiles * 2 > cus) return 0;                        // the plain kernels already fill half the device
+  const int nk = K / 64;
+  int S = (int)(cus / tiles);
+  if (S > nk / 8) S = nk / 8;                           // at least 8 K-steps per range: the pipeline fill is ~3
+  if (S > 8) S = 8;
+  while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;      // every range non-empty
+  return S >= 2 ? S : 0;
+}
+
+// 1 = launched (two launches), 0 = not covered
+int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, int M, int N, int K, int ldx, int ldo,
+                           int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s) {
+  if (splits < 2 || (epilogue != LL_EPI_BIAS && epilogue != LL_EPI_BIAS_RES) || (ldx % 8) != 0 || (ldo % 8) != 0) return 0;
+  if ((long long)256 * ldx * 2 >= 0x7fffffffLL || (long long)256 * K * 2 >= 0x7fffffffLL) return 0;
+  static bool attr = false;
+  const int lds = 3 * 128 * 128 + 4 * 2 * 8192;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_asm_128_partial, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  const int ntm = (M + 255) / 256, ntn = N / 128, per = (K / 64 + splits - 1) / splits;
+  const bf16* nullb = nullptr;
+  bf16* ws = (bf16*)workspace;
+  bf16* nov = nullptr;
+  int zero = 0, ldw = N, flen = 0;
+  void* args[] = {(void*)&x, (void*)&w, (void*)&nullb, (void*)&ws, (void*)&nullb, (void*)&nullb, (void*)&M, (void*)&N, (void*)&K,
+                  (void*)&ldx, (void*)&ldw, (void*)&flen, (void*)&zero, (void*)&ntm, (void*)&ntn, (void*)&gm,
+                  (void*)&nov, (void*)&per, (void*)&zero, (void*)&zero, (void*)&zero, (void*)&zero};
+  (void)hipLaunchKernel((const void*)gemm_asm_128_partial, dim3(ntm * ntn * splits), dim3(256), args, (size_t)lds, s);
+  const long long threads = (long long)M * (N / 8);
+  dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  if (epilogue == LL_EPI_BIAS_RES)
+    hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS_RES>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);
+  else
+    hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);
+  return 1;
 }

@@ -6,7 +6,14 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
                                                   int gm, bf16* __restrict__ v_out, int v_col0, int v_C, int v_shift, int v_lo,
                                                   int v_hi) {
   int mt, nt;
+#ifdef GA_PARTIAL
+  // one K-range of a split-K call: logical ids [split][tile], consecutive ids (one XCD) share the K-range and neighbouring panels;
+  // v_col0 carries the number of K-steps per split, Y is the fp32 workspace [splits][M][ldo], ldo in floats
+  const int ntiles = ntm * ntn, lid = xcd_remap(blockIdx.x, gridDim.x), split = lid / ntiles;
+  tile_of(lid - split * ntiles, ntm, ntn, gm, mt, nt);
+#else
   tile_of(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, gm, mt, nt);
+#endif
   const int m0 = mt * 256, n0 = nt * (GA_WN);
   unsigned long long xb = (unsigned long long)(X + (size_t)m0 * ldx), wb = (unsigned long long)(W + (size_t)n0 * K);
   unsigned long long yb = (unsigned long long)(Y + (size_t)m0 * ldo + n0), bb = (unsigned long long)(bias + n0);
@@ -15,6 +22,15 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
   unsigned rows = (unsigned)(M - m0), cols = (unsigned)(N - n0), nk = (unsigned)(K / 64);
   unsigned flen = (unsigned)(frame_len > 0 ? frame_len : 1), gstride = (unsigned)gate_stride, um0 = (unsigned)m0;
   unsigned tid = threadIdx.x, row_lo = 0;
+#ifdef GA_PARTIAL
+  {
+    const int per = v_col0, k0 = split * per, left = K / 64 - k0;
+    nk = (unsigned)(left < per ? left : per);
+    xb += (unsigned long long)k0 * 128ull; wb += (unsigned long long)k0 * 128ull;
+    yb = (unsigned long long)((float*)Y + ((size_t)split * M + m0) * ldo + n0);
+    ldo_b = (unsigned)ldo * 4u;
+  }
+#else
   if (v_out != nullptr && n0 >= v_col0) {
     // a V tile of the fused QKV projection (one batch element): token t -> cache row t + v_shift for v_lo <= t < v_hi (epi_dest)
     const int hi = (M < v_hi ? M : v_hi) - m0, lo = v_lo > m0 ? v_lo - m0 : 0;
@@ -23,6 +39,7 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
     yb = (unsigned long long)(v_out + ((long long)m0 + v_shift) * (long long)v_C + (n0 - v_col0));
     ldo_b = (unsigned)v_C * 2u;
   }
+#endif
   asm volatile(
 #include GA_INC
       :

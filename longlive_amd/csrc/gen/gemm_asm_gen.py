@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from attn_asm_gen import Gen, finalize, lint, sreg, vreg, areg, to_inc, f32bits, spread   # noqa: E402
 
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_RES = 0, 1, 2, 3
+EPI_PARTIAL = 4                                                   # no epilogue: the raw fp32 accumulators (one K-range of a split-K call), Y = float [rows, ldo / 4]
 
 # ---- inputs (pinned by the HIP wrapper) ----------------------------------------------------------------------------
 S_X, S_W, S_Y, S_BIAS, S_RES, S_GATE = 8, 10, 12, 14, 16, 18      # 64-bit bases (bytes): X row m0; W row n0; Y / RES at (m0, n0); bias + n0;
@@ -90,7 +91,7 @@ class Cfg:
         self.V_E0 = top                                           # the first block's gate / residual pieces (16 registers) when nl
         top += 16 if self.nl else 0
         self.V_EB = top                                           # early bias [nb][g4], 2 registers each
-        self.early_nb = max(0, min(self.NB, (256 - top) // 8))
+        self.early_nb = 0 if epi == EPI_PARTIAL else max(0, min(self.NB, (256 - top) // 8))
 
     def acc(self, mb, nb):
         return (mb * self.NB + nb) * 16
@@ -386,6 +387,18 @@ def gen_epilogue(g: Gen, c: Cfg):
         cons[name] = s0
     if epi == EPI_GELU:
         const_pair("k1", K1, 54); const_pair("k0", K0, 56); const_pair("ce", CEXP, 58); const_pair("one", 1.0, 60)
+    if epi == EPI_PARTIAL:
+        # fp32 accumulators as they stand: a lane owns row m, columns 32 nb + 8 g4 + 4 h + (0..3) = 16 contiguous bytes per group
+        for nb in range(c.NB):
+            for mb in range(c.MB):
+                a0 = c.acc(mb, nb)
+                for r in range(16):
+                    I(f"v_accvgpr_read_b32 {vreg(T + r)}, {areg(a0 + r)}")
+                I(f"s_mov_b64 exec, {sreg(S_MSK + 2 * mb, 2)}")
+                for g4 in range(4):
+                    I(f"global_store_dwordx4 {vreg(EA + mb)}, {vreg(T + 4 * g4, 4)}, {sreg(S_Y, 2)} offset:{128 * nb + 32 * g4}")
+                I("s_mov_b64 exec, -1")
+        return
     # Every global read of the epilogue is issued ahead of its use: the early ones before the loop (gen_epilogue_setup), here the
     # bias vectors that did not fit up there, then the gate / residual pieces of block j + 1 while block j computes.
     BB, PB = T + 72, T + 72 + 8 * c.NB                                       # late bias raw [nb][g4] (2 registers each); block buffers P[2][16]

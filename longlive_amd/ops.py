@@ -249,7 +249,12 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
             assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
-    if splitk:
+    if not splitk and M * N <= (1 << 22) and epilogue in (EPI_BIAS, EPI_BIAS_RES) and _ksplit_plan(lib, M, N, K):
+        # few rows (the text side: umT5 at 512 tokens, text K / V projections): K cut into ranges so that the grid fills the device
+        ws = ksplit_workspace(x.device, M, N, K)
+        _lib.check(lib.ll_gemm_bf16_ksplit(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
+                                           _ptr(res), ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_bf16_ksplit")
+    elif splitk:
         ws = splitk_workspace(x.device, M, N)
         _lib.check(lib.ll_gemm_bf16_splitk(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                            _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len,
@@ -263,6 +268,26 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
 
 
 _splitk_ws = {}
+_ksplit_ws = {}
+_ksplit_plans = {}
+
+
+def _ksplit_plan(lib, M: int, N: int, K: int) -> int:
+    key = (M, N, K)
+    if key not in _ksplit_plans:
+        _ksplit_plans[key] = int(lib.ll_gemm_ksplit_plan(M, N, K))
+    return _ksplit_plans[key]
+
+
+def ksplit_workspace(device, M: int, N: int, K: int) -> torch.Tensor:
+    """Scratch for ll_gemm_bf16_ksplit ([splits][M][N] fp32 tile sums; needs no initialisation), one buffer per (device, stream)."""
+    need = int(_lib.load().ll_gemm_ksplit_workspace_bytes(M, N, K))
+    key = (device.type, device.index, int(_stream() or 0))
+    buf = _ksplit_ws.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+        _ksplit_ws[key] = buf
+    return buf
 
 
 def splitk_workspace(device, M: int, N: int) -> torch.Tensor:

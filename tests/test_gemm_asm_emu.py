@@ -41,14 +41,15 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
     gate = bf(0.5 * rng.standard_normal((nframes, N)))
     mem = E.Memory()
     ax, aw, ab, ar, ag = mem.alloc(x), mem.alloc(w), mem.alloc(bias), mem.alloc(res), mem.alloc(gate)
-    ay = mem.alloc(np.full((rows_valid, N), 0x7FC0, dtype=np.uint16))
+    partial = epi == G.EPI_PARTIAL
+    ay = mem.alloc(np.full((rows_valid, N), np.nan, dtype=np.float32) if partial else np.full((rows_valid, N), 0x7FC0, dtype=np.uint16))
     m = E.Machine(text, mem, 4, mode=mode, lds_bytes=G.Cfg(WN, epi).lds_bytes)
     for wv in m.waves:
         s = wv.s
         def put64(i, val):
             s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
         put64(G.S_X, ax); put64(G.S_W, aw); put64(G.S_Y, ay); put64(G.S_BIAS, ab); put64(G.S_RES, ar); put64(G.S_GATE, ag)
-        s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K * 2, K * 2, N * 2
+        s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K * 2, K * 2, N * (4 if partial else 2)
         s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 64
         s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
         s[G.S_ROWLO] = row_lo
@@ -56,8 +57,10 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
         wv.v[1:] = 0x7FC0BEEF
         wv.a[:] = 0x7FC0BEEF
     m.run()
-    got = f32(mem.get(ay).view(np.uint16).reshape(rows_valid, N)).astype(np.float64)
     acc = (f32(x).astype(np.float64) @ f32(w).astype(np.float64).T).astype(np.float32)
+    if partial:                                       # one K-range of a split-K call: the fp32 accumulators as they stand
+        return mem.get(ay).view(np.float32).reshape(rows_valid, N).astype(np.float64), acc.astype(np.float64)
+    got = f32(mem.get(ay).view(np.uint16).reshape(rows_valid, N)).astype(np.float64)
     v = rbf(acc + f32(bias)[None, :])
     if epi == G.EPI_BIAS:
         want = v
@@ -119,6 +122,12 @@ def test_gemm_asm_shortest_k_and_single_row(rows_valid, K):
     got, want = run_case(128, G.EPI_GATE_RES, "lazy", rows_valid=rows_valid, K=K, m0=0, frame_len=40)
     assert np.isfinite(got).all()
     assert (got == want).mean() > 0.95 and np.abs(got - want).max() < 0.07
+
+
+def test_gemm_asm_partial_sums_for_split_k():
+    """EPI_PARTIAL: the kernel of the small-M split-K path stores its fp32 accumulators (rows past M untouched)."""
+    got, want = run_case(128, G.EPI_PARTIAL, "lazy", rows_valid=100, K=512)
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
 def test_gemm_asm_text_assembles(tmp_path):

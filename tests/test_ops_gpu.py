@@ -596,6 +596,38 @@ def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
             assert rel_l2(got.cpu(), ref) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(512, 4096, 4096, "res"), (512, 8192, 4096, "bias"), (4096, 512, 4096, "bias"),
+                                       (512, 4096, 10240, "res"), (77, 1536, 4096, "bias"), (300, 256, 1024, "res")])
+def test_gemm_small_m_split_k_matches_plain(ops, M, N, K, epi):
+    """ll_gemm_bf16_ksplit (umT5's linears at 512 tokens, the text K / V projections): K cut into ranges on the generated 256 x 128
+    kernel, fp32 tile sums added in a fixed order -> equal to the unsplit HIP kernel up to the order of the fp32 sum, bit-identical
+    run to run; ops.gemm takes it by itself for these shapes."""
+    from longlive_amd import _lib
+    lib = _lib.load()
+    S = lib.ll_gemm_ksplit_plan(M, N, K)
+    assert S >= 2, (M, N, K, S)
+    x = hn("kx", (M, K)).to(DEV)
+    w = (hn("kw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("kb", (N,), 0.1).to(DEV)
+    kw = {"res": hn("kr", (M, N)).to(DEV)} if epi == "res" else {}
+    code = ops.EPI_BIAS_RES if epi == "res" else ops.EPI_BIAS
+    got = ops.gemm(x, w, b, code, **kw)
+    again = ops.gemm(x, w, b, code, **kw)
+    assert torch.equal(got, again)
+    try:
+        _set_tuning("gemm_asm", 0)                       # plan -> 0: the HIP kernels, unsplit
+        ops._ksplit_plans.clear()
+        assert lib.ll_gemm_ksplit_plan(M, N, K) == 0
+        want = ops.gemm(x, w, b, code, **kw)
+    finally:
+        _set_tuning("gemm_asm", 3)
+        ops._ksplit_plans.clear()
+    assert_bf16_close(got, want, 2, 0.97, f"small-M split-K {M}x{N}x{K} {epi}", atol=4e-2 if epi == "res" else None)
+    ref = (x.double() @ w.double().t() + b.double()).cpu()
+    if epi == "bias":
+        assert rel_l2(got.cpu(), ref) < 4e-3
+
+
 def test_gemm_splitk_handoff_is_fresh_across_launches(ops, splitk_kernel):
     """The partial tiles live at fixed workspace addresses: alternate two different activations so that a partner reading the
     PREVIOUS launch's bytes (a stale line somewhere between the two workgroups) cannot reproduce the right answer."""
