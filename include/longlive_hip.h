@@ -162,6 +162,13 @@ int ll_gemm_ksplit_plan(int M, int N, int K);
 long long ll_gemm_ksplit_workspace_bytes(int M, int N, int K);
 int ll_gemm_bf16_ksplit(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
                         int ldo, int epilogue, const ll_bf16* res, void* workspace, long long workspace_bytes, ll_stream stream);
+/* ll_gemm_bf16_ksplit (LL_EPI_BIAS_RES) followed by T5LayerNorm of the new residual stream (wan/modules/t5.py:57-63,119-160:
+ * x = x + linear(.); h = norm(x)): out = x_new [M, N] (ldo = N), h_out = bf16(norm_w * bf16(x_new * rsqrt(mean(x_new^2) + eps))).
+ * On the small-M path the K-range sum, bias, residual and norm are one pass over each row; otherwise ll_gemm_bf16 +
+ * ll_t5_rmsnorm.  The two outputs carry the same bits either way. */
+int ll_gemm_bf16_ksplit_t5norm(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
+                               int ldo, const ll_bf16* res, const ll_bf16* norm_w, float eps, ll_bf16* h_out, void* workspace,
+                               long long workspace_bytes, ll_stream stream);
 
 /* W8A8 variant of ll_gemm_bf16 for BASELINE config 5 ("INT8-quantized linear layers"; the reference ships no INT8 code,
  * reports.md:24,39): out = epilogue(sx[m] * sw[n] * (xq[M,K] . wq[N,K]^T) + bias) with int8 operands, exact int32

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ll_gemm_ksplit_plan": [_i, _i, _i],
     "ll_gemm_ksplit_workspace_bytes": [_i, _i, _i],
     "ll_gemm_bf16_ksplit": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _ll, _p],
+    "ll_gemm_bf16_ksplit_t5norm": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _ll, _p],
     "ll_gemm_splitk_status": [_p, _p, _p],
     "ll_gemm_w8a8_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],

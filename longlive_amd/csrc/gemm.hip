@@ -869,7 +869,9 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
 int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool has_v, bool v_ok, int frame_len);
 int gemm_ksplit_splits(int M, int N, int K, int cus);
 int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, int M, int N, int K, int ldx, int ldo,
-                           int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s);
+                           int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s, const bf16* norm_w,
+                           float eps, bf16* h_out);
+extern "C" int ll_t5_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, float eps, ll_stream stream);
 const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap);
 static bool gemm_asm_wanted(int epilogue) {
   return (g_gemm_asm & 1) && !((g_gemm_asm & 4) && epilogue == LL_EPI_BIAS_GELU) && !((g_gemm_asm & 8) && epilogue != LL_EPI_BIAS_GELU);
@@ -1027,12 +1029,40 @@ extern "C" int ll_gemm_bf16_ksplit(const ll_bf16* x, const ll_bf16* w, const ll_
     LL_REQUIRE(workspace_bytes >= (long long)S * M * N * 4 && ((size_t)workspace & 15) == 0,
                "ll_gemm_bf16_ksplit: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes, (long long)S * M * N * 4);
     if (gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, epilogue,
-                               (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream))
+                               (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream, nullptr, 0.f, nullptr))
       return ll_check_launch("ll_gemm_bf16_ksplit");
   }
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
   launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream);
   return ll_check_launch("ll_gemm_bf16_ksplit");
+}
+
+// ll_gemm_bf16_ksplit with LL_EPI_BIAS_RES followed by the T5 RMSNorm of the new residual stream (wan/modules/t5.py:57-63,119-160:
+// x = x + linear(...); h = norm(x)): out = x_new [M, ldo], h_out = T5LayerNorm(x_new) [M, N].  On the small-M path the K-range sum,
+// bias, residual and the norm are ONE pass over the row; otherwise it is ll_gemm_bf16 + ll_t5_rmsnorm.  Same bits either way.
+extern "C" int ll_gemm_bf16_ksplit_t5norm(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K,
+                                          int ldx, int ldo, const ll_bf16* res, const ll_bf16* norm_w, float eps, ll_bf16* h_out,
+                                          void* workspace, long long workspace_bytes, ll_stream stream) {
+  LL_REQUIRE(K > 0 && K % 64 == 0, "ll_gemm_bf16_ksplit_t5norm: K=%d must be a positive multiple of 64", K);
+  LL_REQUIRE(ldx >= K && ldx % 8 == 0, "ll_gemm_bf16_ksplit_t5norm: ldx=%d must be >= K and a multiple of 8", ldx);
+  LL_REQUIRE(norm_w != nullptr && h_out != nullptr, "ll_gemm_bf16_ksplit_t5norm: needs the norm weight and an output for the normalised rows");
+  LL_REQUIRE(ldo == N, "ll_gemm_bf16_ksplit_t5norm: ldo=%d must equal N=%d (the norm runs over whole rows)", ldo, N);
+  int rc = check_epilogue("ll_gemm_bf16_ksplit_t5norm", M, N, ldo, LL_EPI_BIAS_RES, bias, res, nullptr, nullptr, 0, 0, 0, 0);
+  if (rc) return rc;
+  LL_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "ll_gemm_bf16_ksplit_t5norm: workspace_bytes without a workspace");
+  if (M == 0) return LL_OK;
+  const int S = ll_gemm_ksplit_plan(M, N, K);
+  if (S >= 2 && workspace != nullptr && N <= 4096 && N % 512 == 0) {
+    LL_REQUIRE(workspace_bytes >= (long long)S * M * N * 4 && ((size_t)workspace & 15) == 0,
+               "ll_gemm_bf16_ksplit_t5norm: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes, (long long)S * M * N * 4);
+    if (gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, LL_EPI_BIAS_RES,
+                               (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream, (const bf16*)norm_w, eps,
+                               (bf16*)h_out))
+      return ll_check_launch("ll_gemm_bf16_ksplit_t5norm");
+  }
+  rc = ll_gemm_bf16_ksplit(x, w, bias, out, M, N, K, ldx, ldo, LL_EPI_BIAS_RES, res, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  return ll_t5_rmsnorm(out, norm_w, h_out, M, N, eps, stream);
 }
 
 // Split-K form of ll_gemm_bf16 (gemm_kernel_v4sk): same arguments plus a workspace.  Taken when N is a multiple of 256, K a

@@ -11,6 +11,13 @@
 #undef GA_NAME
 #undef GA_WN
 #undef GA_INC
+#define GA_NAME gemm_asm_256_bias
+#define GA_WN 256
+#define GA_INC "build/gemm_asm_256_0.inc"
+#include "gemm_asm_kernel.inl"
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
 #define GA_NAME gemm_asm_192_bias
 #define GA_WN 192
 #define GA_INC "build/gemm_asm_192_0.inc"
@@ -60,6 +67,8 @@ int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool 
   if (has_v) return (v_ok && epilogue == LL_EPI_BIAS && N % 192 == 0) ? 192 : 0;
   if (epilogue == LL_EPI_BIAS_GELU) return N % 224 == 0 ? 224 : 0;
   if (epilogue == LL_EPI_BIAS && N > 2048 && N % 192 == 0) return 192;
+  if (epilogue == LL_EPI_BIAS && M <= 1024 && N >= 16384 && N % 256 == 0) return 256;      // umT5's gated FFN (512 x 20480 x 4096): 160 tiles of 256 x 256 in ONE round,
+                                                                                             // half the L2 bytes per FLOP of the 128-wide kernel (which is L2-bound at ~29 B/clk/CU)
   if (N % 128 == 0 && (N <= 2048 || M <= 1024) &&      // wide outputs of few rows (umT5's gated FFN, 512 x 20480): the HIP choice there is 256 x 128 as well
       (epilogue == LL_EPI_BIAS || epilogue == LL_EPI_BIAS_GATE_RES || epilogue == LL_EPI_BIAS_RES)) return 128;
   return 0;
@@ -73,11 +82,12 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
   const int wn = gemm_asm_width(M, N, K, ldx, epilogue, ea.sx == nullptr && ea.mod == nullptr, has_v, v_ok, ea.frame_len);
   if (!wn) return 0;
   const void* fn = wn == 224 ? (const void*)gemm_asm_224_gelu
+                   : wn == 256 ? (const void*)gemm_asm_256_bias
                    : wn == 192 ? (const void*)gemm_asm_192_bias
                    : epilogue == LL_EPI_BIAS ? (const void*)gemm_asm_128_bias
                    : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asm_128_gate_res : (const void*)gemm_asm_128_res;
-  static bool attr[5] = {false, false, false, false, false};
-  const int slot = wn == 224 ? 0 : wn == 192 ? 4 : fn == (const void*)gemm_asm_128_bias ? 1 : fn == (const void*)gemm_asm_128_gate_res ? 2 : 3;
+  static bool attr[6] = {false, false, false, false, false, false};
+  const int slot = wn == 224 ? 0 : wn == 256 ? 5 : wn == 192 ? 4 : fn == (const void*)gemm_asm_128_bias ? 1 : fn == (const void*)gemm_asm_128_gate_res ? 2 : 3;
   const int lds = 3 * wn * 128 + 4 * 2 * 8192;      // gen/gemm_asm_gen.py Cfg.lds_bytes: 3 W slots of WN rows x 128 B + 2 X units of 8 KiB per wave
   if (!attr[slot]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr[slot] = true; }
   const int ntm = (M + 255) / 256, ntn = N / wn;
@@ -94,7 +104,7 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
 }
 
 const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap) {
-  const char* tail = wn == 224 ? "gelu" : epilogue == LL_EPI_BIAS ? "bias" : epilogue == LL_EPI_BIAS_GATE_RES ? "gate_res" : "res";      // wn == 192: bias
+  const char* tail = wn == 224 ? "gelu" : wn == 256 ? "bias" : epilogue == LL_EPI_BIAS ? "bias" : epilogue == LL_EPI_BIAS_GATE_RES ? "gate_res" : "res";      // wn == 192: bias
   snprintf(out, (size_t)cap, "gemm_asm_%d_%s<bf16> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", wn,
            tail, wn, ((M + 255) / 256) * (N / wn));
   return out;
@@ -132,6 +142,56 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(const float* __
   *reinterpret_cast<bf16x8*>(out + (size_t)m * ldo + n) = o;
 }
 
+// The same pass for the residual stream of umT5 (t5.py:119-160: x = x + linear(...); h = T5LayerNorm(x)): one wave per row sums the
+// K-ranges, adds bias and residual (x_new, written to `out`) and applies the T5 RMSNorm to that row at once (h_out) -- the
+// arithmetic, its order and its rounding points are gemm_ksplit_reduce_kernel's followed by t5_rmsnorm_kernel's (t5.hip), so the
+// pair of outputs is bit-identical to the two launches it replaces.  N <= 4096, N % 512 == 0.
+__global__ __launch_bounds__(256) void gemm_ksplit_reduce_norm_kernel(const float* __restrict__ part, int splits, int M, int N,
+                                                                      const bf16* __restrict__ bias, const bf16* __restrict__ res,
+                                                                      bf16* __restrict__ out, int ldo, const bf16* __restrict__ nw,
+                                                                      float eps, bf16* __restrict__ h_out) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  bf16x8 xn[8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = lane * 8 + 512 * i;
+    if (n < N) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int s = 0; s < splits; ++s) {
+        const float4* p = reinterpret_cast<const float4*>(part + ((size_t)s * M + m) * N + n);
+        float4 a = p[0], b = p[1];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+      }
+      bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + n), rv = *reinterpret_cast<const bf16x8*>(res + (size_t)m * ldo + n), o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16 v = (bf16)(acc[j] + (float)bv[j]);
+        o[j] = (bf16)((float)rv[j] + (float)v);
+        ss += (float)o[j] * (float)o[j];
+      }
+      xn[i] = o;
+      *reinterpret_cast<bf16x8*>(out + (size_t)m * ldo + n) = o;
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)N + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int n = lane * 8 + 512 * i;
+    if (n < N) {
+      bf16x8 g = *reinterpret_cast<const bf16x8*>(nw + n), o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)g[j] * rbf((float)xn[i][j] * r));
+      *reinterpret_cast<bf16x8*>(h_out + (size_t)m * N + n) = o;
+    }
+  }
+}
+
 // splits the small-M path would use for this shape on a device of `cus` compute units; 0 = not taken
 int gemm_ksplit_splits(int M, int N, int K, int cus) {
   if (M <= 0 || N <= 0 || N % 128 != 0 || K % 64 != 0 || K < 1024 || cus <= 0) return 0;
@@ -147,7 +207,8 @@ int gemm_ksplit_splits(int M, int N, int K, int cus) {
 
 // 1 = launched (two launches), 0 = not covered
 int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, int M, int N, int K, int ldx, int ldo,
-                           int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s) {
+                           int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s, const bf16* norm_w,
+                           float eps, bf16* h_out) {
   if (splits < 2 || (epilogue != LL_EPI_BIAS && epilogue != LL_EPI_BIAS_RES) || (ldx % 8) != 0 || (ldo % 8) != 0) return 0;
   if ((long long)256 * ldx * 2 >= 0x7fffffffLL || (long long)256 * K * 2 >= 0x7fffffffLL) return 0;
   static bool attr = false;
@@ -164,7 +225,10 @@ int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16*
   (void)hipLaunchKernel((const void*)gemm_asm_128_partial, dim3(ntm * ntn * splits), dim3(256), args, (size_t)lds, s);
   const long long threads = (long long)M * (N / 8);
   dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-  if (epilogue == LL_EPI_BIAS_RES)
+  if (norm_w != nullptr)       // (the caller checked: bias + residual, N <= 4096, N % 512 == 0)
+    hipLaunchKernelGGL(gemm_ksplit_reduce_norm_kernel, dim3((M + 3) / 4), block, 0, s, (const float*)workspace, splits, M, N, bias, res,
+                       out, ldo, norm_w, eps, h_out);
+  else if (epilogue == LL_EPI_BIAS_RES)
     hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS_RES>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);
   else
     hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);

@@ -661,6 +661,26 @@ def t5_rmsnorm(x, w, eps: float = 1e-6):
     return out
 
 
+def gemm_res_t5norm(x, w, bias, res, norm_w, eps: float = 1e-6, tag: str = "gemm"):
+    """(x_new, h) = (res + (x @ w^T + bias), T5LayerNorm(x_new; norm_w)): umT5's `x = x + linear(.)` and the norm that follows it
+    (t5.py:119-160) -- on the small-M path one pass over the rows does the K-range sum, bias, residual and norm."""
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias"); _chk(res, "res"); _chk(norm_w, "norm_w")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape == (N, K) and bias.numel() == N and res.numel() == M * N and norm_w.numel() == N
+    out = torch.empty(*x.shape[:-1], N, dtype=bf16, device=x.device)
+    h = torch.empty_like(out)
+    lib = _lib.load()
+    ws = ksplit_workspace(x.device, M, N, K) if _ksplit_plan(lib, M, N, K) else None
+    t0 = _t0(tag)
+    _lib.check(lib.ll_gemm_bf16_ksplit_t5norm(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, res.data_ptr(),
+                                              norm_w.data_ptr(), float(eps), h.data_ptr(), _ptr(ws), ws.numel() if ws is not None else 0,
+                                              _stream()), "ll_gemm_bf16_ksplit_t5norm")
+    _t1(tag, t0, 2.0 * M * N * K)
+    return out, h
+
+
 def t5_gated_gelu(h):
     """h [M, 2F] = [gate | fc1] -> bf16(fc1 * GELU_py(gate)) [M, F]."""
     _chk(h, "h")

@@ -112,16 +112,18 @@ class UMT5EncoderHIP(nn.Module):
             if n < 1 or not bool((m[:n] > 0).all()):
                 raise RuntimeError("UMT5EncoderHIP: mask must be a non-empty prefix (right-padded prompts)")
             x = ops.gather_rows(self._p("token_embedding.weight"), ids_d[b].contiguous())
-            for ly in self._layers:
-                h = ops.t5_rmsnorm(x, ly["n1"])
+            h = ops.t5_rmsnorm(x, self._layers[0]["n1"])
+            for i, ly in enumerate(self._layers):
                 qk = ops.gemm(h, ly["wqk"], zq[2 * c.dim_attn])
                 vt = ops.gemm(ly["wv"], h, zq[L])                                    # [dim_attn, L] = Wv h^T
                 a = ops.t5_attention(qk, vt, ly["bias"], c.num_heads, n)
-                x = ops.gemm(a, ly["wo"], zq[c.dim], epilogue=ops.EPI_BIAS_RES, res=x)
-                h = ops.t5_rmsnorm(x, ly["n2"])
+                # x = x + o(a); h = norm2(x)   and   x = x + w2(g); h = the next layer's norm1(x) (the encoder's final norm after
+                # the last layer): the residual update and the norm that follows it are one call (same bits as the two kernels)
+                x, h = ops.gemm_res_t5norm(a, ly["wo"], zq[c.dim], x, ly["n2"])
                 g = ops.t5_gated_gelu(ops.gemm(h, ly["wgf"], zq[2 * c.dim_ffn]))
-                x = ops.gemm(g, ly["w2"], zq[c.dim], epilogue=ops.EPI_BIAS_RES, res=x)
-            outs.append(ops.t5_rmsnorm(x, self._p("norm.weight")))
+                nxt = self._layers[i + 1]["n1"] if i + 1 < len(self._layers) else self._p("norm.weight")
+                x, h = ops.gemm_res_t5norm(g, ly["w2"], zq[c.dim], x, nxt)
+            outs.append(h)
         return torch.stack(outs, 0)
 
 

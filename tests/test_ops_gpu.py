@@ -557,7 +557,7 @@ def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi, splitk_kernel):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4680, 8960, 1536, "gelu"), (4680, 1536, 1536, "gate"), (4680, 1536, 1536, "res"),
-                                       (4680, 1536, 1536, "bias"), (4680, 1536, 8960, "gate"), (300, 224, 256, "gelu"),
+                                       (4680, 1536, 1536, "bias"), (4680, 1536, 8960, "gate"), (300, 224, 256, "gelu"), (512, 20480, 4096, "bias"),
                                        (70, 128, 256, "bias"), (9360, 1536, 1536, "gate"), (513, 448, 320, "gelu")])
 def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
     """The generated one-wave-per-SIMD GEMM kernels (tuning key gemm_asm; gen/gemm_asm_gen.py) against the HIP kernels they replace,
@@ -626,6 +626,22 @@ def test_gemm_small_m_split_k_matches_plain(ops, M, N, K, epi):
     ref = (x.double() @ w.double().t() + b.double()).cpu()
     if epi == "bias":
         assert rel_l2(got.cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 4096, 4096), (512, 4096, 10240), (77, 1024, 2048), (300, 1536, 1024)])
+def test_gemm_residual_t5norm_is_the_two_kernels(ops, M, N, K):
+    """ll_gemm_bf16_ksplit_t5norm: x_new = res + linear(x), h = T5LayerNorm(x_new) in one pass over the rows on the small-M path --
+    both outputs bit-identical to ops.gemm(EPI_BIAS_RES) + ops.t5_rmsnorm (the fused pass keeps their order of operations)."""
+    x = hn("tx", (M, K)).to(DEV)
+    w = (hn("tw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("tb", (N,), 0.1).to(DEV)
+    res = hn("tr", (M, N)).to(DEV)
+    nw = hn("tn", (N,), 0.2, 1.0).to(DEV)
+    want_x = ops.gemm(x, w, b, ops.EPI_BIAS_RES, res=res)
+    want_h = ops.t5_rmsnorm(want_x, nw)
+    got_x, got_h = ops.gemm_res_t5norm(x, w, b, res, nw)
+    assert torch.equal(got_x, want_x), (got_x.float() - want_x.float()).abs().max().item()
+    assert torch.equal(got_h, want_h), (got_h.float() - want_h.float()).abs().max().item()
 
 
 def test_gemm_splitk_handoff_is_fresh_across_launches(ops, splitk_kernel):
