@@ -66,6 +66,11 @@ def test_no_torch_types_in_the_abi():
     (lambda L: L.ll_gemm_bf16_splitk(0, 0, 1, 0, 4680, 1536, 8960, 8960, 1536, 3, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "needs res"),
     (lambda L: L.ll_gemm_w8a8_splitk(0, 0, 0, 0, 1, 0, 4680, 1536, 8960, 1536, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "scales"),
     (lambda L: L.ll_conv_cl(0, 1, 1, 1, 0, 1, 2, 16, 32, 96, 96, 2624, 3, 3, 0, 96, None), "null operand"),
+    (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 1, 0, None, 0, None), "bias or bias + residual"),
+    (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 3, 0, None, 0, None), "needs res"),
+    (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 0, 0, None, 64, None), "without a workspace"),
+    (lambda L: L.ll_gemm_bf16_ksplit_t5norm(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 1, None, 1e-6, None, None, 0, None), "norm weight"),
+    (lambda L: L.ll_gemm_bf16_ksplit_t5norm(0, 0, 1, 0, 512, 4096, 4096, 4096, 4100, 1, 1, 1e-6, 1, None, 0, None), "must equal N"),
 ])
 def test_invalid_arguments_are_rejected_before_launch(call, needle):
     lib = _lib.load()
@@ -86,6 +91,7 @@ def test_splitk_workspace_size_and_plan_without_a_gpu():
     import torch
     if not torch.cuda.is_available():
         assert lib.ll_gemm_splitk_plan(4680, 1536, 8960, 0) == 0
+        assert lib.ll_gemm_ksplit_plan(512, 4096, 4096) == 0 and lib.ll_gemm_ksplit_workspace_bytes(512, 4096, 4096) == 0
 
 
 def test_gemm_plan_names_the_kernel_family_a_call_takes():
