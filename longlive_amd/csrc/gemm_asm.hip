@@ -192,17 +192,20 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_norm_kernel(const floa
   }
 }
 
-// splits the small-M path would use for this shape on a device of `cus` compute units; 0 = not taken
+// K-ranges the small-M path cuts this call into on a device of `cus` compute units; 0 = not taken.  The NUMBER of ranges depends
+// on N and K only (the order of the fp32 sum must not change with the batch: M = 512 and M = 1024 give the same bits per row);
+// M only decides whether the path is taken at all (the plain kernels would fill less than half of the device).
 int gemm_ksplit_splits(int M, int N, int K, int cus) {
   if (M <= 0 || N <= 0 || N % 128 != 0 || K % 64 != 0 || K < 1024 || cus <= 0) return 0;
   const long long tiles = (long long)((M + 255) / 256) * (N / 128);
   if (tiles * 2 > cus) return 0;                        // the plain kernels already fill half the device
   const int nk = K / 64;
-  int S = (int)(cus / tiles);
+  int S = (int)((long long)cus * 64 / N);               // fills the device at 512 rows (tiles = N / 64 there)
+  if (S > 4) S = 4;
   if (S > nk / 8) S = nk / 8;                           // at least 8 K-steps per range: the pipeline fill is ~3
-  if (S > 8) S = 8;
   while (S >= 2 && (S - 1) * ((nk + S - 1) / S) >= nk) --S;      // every range non-empty
-  return S >= 2 ? S : 0;
+  if (S < 2 || tiles * S > 2 * cus) return 0;
+  return S;
 }
 
 // 1 = launched (two launches), 0 = not covered

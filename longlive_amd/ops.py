@@ -269,14 +269,12 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
 
 _splitk_ws = {}
 _ksplit_ws = {}
-_ksplit_plans = {}
 
 
 def _ksplit_plan(lib, M: int, N: int, K: int) -> int:
-    key = (M, N, K)
-    if key not in _ksplit_plans:
-        _ksplit_plans[key] = int(lib.ll_gemm_ksplit_plan(M, N, K))
-    return _ksplit_plans[key]
+    """K-ranges the small-M path would use (0 = not taken).  Asked per call: the answer follows the library's tuning, and only
+    calls with few rows get here (the DiT's block linears do not)."""
+    return int(lib.ll_gemm_ksplit_plan(M, N, K))
 
 
 def ksplit_workspace(device, M: int, N: int, K: int) -> torch.Tensor:
