@@ -628,6 +628,21 @@ def test_gemm_small_m_split_k_matches_plain(ops, M, N, K, epi):
         assert rel_l2(got.cpu(), ref) < 4e-3
 
 
+def test_gemm_small_m_split_k_is_batch_invariant(ops):
+    """The number of K-ranges depends on N and K only: the text K / V projection of two prompts batched (M = 1024) gives each
+    prompt the bits it gets alone (M = 512) -- what keeps the B = 2 throughput mode bit-identical to two streams."""
+    from longlive_amd import _lib
+    lib = _lib.load()
+    N, K = 1536, 1536
+    assert lib.ll_gemm_ksplit_plan(512, N, K) == lib.ll_gemm_ksplit_plan(1024, N, K) >= 2
+    x = hn("bx", (1024, K)).to(DEV)
+    w = (hn("bw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
+    b = hn("bb", (N,), 0.1).to(DEV)
+    both = ops.gemm(x, w, b)
+    for i in (0, 1):
+        assert torch.equal(both[512 * i:512 * (i + 1)], ops.gemm(x[512 * i:512 * (i + 1)].contiguous(), w, b))
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 4096, 4096), (512, 4096, 10240), (77, 1024, 2048), (300, 1536, 1024)])
 def test_gemm_residual_t5norm_is_the_two_kernels(ops, M, N, K):
     """ll_gemm_bf16_ksplit_t5norm: x_new = res + linear(x), h = T5LayerNorm(x_new) in one pass over the rows on the small-M path --
