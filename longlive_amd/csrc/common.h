@@ -27,6 +27,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// sum over a 256-thread workgroup in a FIXED order (per wave by wave_sum, then ((w0 + w1) + w2) + w3); sh = 4 floats of LDS
+__device__ __forceinline__ float t5_block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
 // gelu(tanh approx) as x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3); identical to 0.5x(1+tanh u).
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;

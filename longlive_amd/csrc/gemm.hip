@@ -1052,7 +1052,7 @@ extern "C" int ll_gemm_bf16_ksplit_t5norm(const ll_bf16* x, const ll_bf16* w, co
   LL_REQUIRE(workspace_bytes >= 0 && (workspace != nullptr || workspace_bytes == 0), "ll_gemm_bf16_ksplit_t5norm: workspace_bytes without a workspace");
   if (M == 0) return LL_OK;
   const int S = ll_gemm_ksplit_plan(M, N, K);
-  if (S >= 2 && workspace != nullptr && N <= 4096 && N % 512 == 0) {
+  if (S >= 2 && workspace != nullptr && N <= 4096) {
     LL_REQUIRE(workspace_bytes >= (long long)S * M * N * 4 && ((size_t)workspace & 15) == 0,
                "ll_gemm_bf16_ksplit_t5norm: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes, (long long)S * M * N * 4);
     if (gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, LL_EPI_BIAS_RES,

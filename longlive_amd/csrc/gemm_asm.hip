@@ -142,22 +142,22 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(const float* __
   *reinterpret_cast<bf16x8*>(out + (size_t)m * ldo + n) = o;
 }
 
-// The same pass for the residual stream of umT5 (t5.py:119-160: x = x + linear(...); h = T5LayerNorm(x)): one wave per row sums the
-// K-ranges, adds bias and residual (x_new, written to `out`) and applies the T5 RMSNorm to that row at once (h_out) -- the
-// arithmetic, its order and its rounding points are gemm_ksplit_reduce_kernel's followed by t5_rmsnorm_kernel's (t5.hip), so the
-// pair of outputs is bit-identical to the two launches it replaces.  N <= 4096, N % 512 == 0.
+// The same pass for the residual stream of umT5 (t5.py:119-160: x = x + linear(...); h = T5LayerNorm(x)): one workgroup per row sums
+// the K-ranges, adds bias and residual (x_new, written to `out`) and applies the T5 RMSNorm to that row at once (h_out) -- the
+// arithmetic, its order and its rounding points are gemm_ksplit_reduce_kernel's followed by t5_rmsnorm_kernel's (t5.hip: thread t
+// owns columns 8 t + 2048 i, t5_block_sum), so the pair of outputs is bit-identical to the two launches it replaces.
+// N <= 4096 (two column groups per thread).
 __global__ __launch_bounds__(256) void gemm_ksplit_reduce_norm_kernel(const float* __restrict__ part, int splits, int M, int N,
                                                                       const bf16* __restrict__ bias, const bf16* __restrict__ res,
                                                                       bf16* __restrict__ out, int ldo, const bf16* __restrict__ nw,
                                                                       float eps, bf16* __restrict__ h_out) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
-  bf16x8 xn[8];
+  __shared__ float sh[4];
+  const int m = blockIdx.x;
+  bf16x8 xn[2];
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n = lane * 8 + 512 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int n = threadIdx.x * 8 + 2048 * i;
     if (n < N) {
       float acc[8];
 #pragma unroll
@@ -178,11 +178,11 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_norm_kernel(const floa
       *reinterpret_cast<bf16x8*>(out + (size_t)m * ldo + n) = o;
     }
   }
-  ss = wave_sum(ss);
+  ss = t5_block_sum(ss, sh);
   const float r = rsqrtf(ss / (float)N + eps);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n = lane * 8 + 512 * i;
+  for (int i = 0; i < 2; ++i) {
+    const int n = threadIdx.x * 8 + 2048 * i;
     if (n < N) {
       bf16x8 g = *reinterpret_cast<const bf16x8*>(nw + n), o;
 #pragma unroll
@@ -228,8 +228,8 @@ int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16*
   (void)hipLaunchKernel((const void*)gemm_asm_128_partial, dim3(ntm * ntn * splits), dim3(256), args, (size_t)lds, s);
   const long long threads = (long long)M * (N / 8);
   dim3 grid((unsigned)((threads + 255) / 256)), block(256);
-  if (norm_w != nullptr)       // (the caller checked: bias + residual, N <= 4096, N % 512 == 0)
-    hipLaunchKernelGGL(gemm_ksplit_reduce_norm_kernel, dim3((M + 3) / 4), block, 0, s, (const float*)workspace, splits, M, N, bias, res,
+  if (norm_w != nullptr)       // (the caller checked: bias + residual, N <= 4096)
+    hipLaunchKernelGGL(gemm_ksplit_reduce_norm_kernel, dim3(M), block, 0, s, (const float*)workspace, splits, M, N, bias, res,
                        out, ldo, norm_w, eps, h_out);
   else if (epilogue == LL_EPI_BIAS_RES)
     hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS_RES>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);

@@ -4,23 +4,25 @@
 // reference's bf16 rounding points first; the GEMMs carry the time.
 #include "gemm_common.h"
 
-// T5LayerNorm.forward (t5.py:57-63): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))), statistics in fp32.  One wave per row.
+// T5LayerNorm.forward (t5.py:57-63): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))), statistics in fp32.  One 256-thread workgroup
+// per row (512 rows: a wave per row left three quarters of the device without a wave): thread t owns columns 8 t + 2048 i; the sum
+// of squares is taken per thread in column order, per wave by shuffles, then ((w0 + w1) + w2) + w3 -- t5_block_sum, shared with
+// gemm_ksplit_reduce_norm_kernel (gemm_asm.hip) so that the fused pass and this kernel give the same bits.
 __global__ __launch_bounds__(256) void t5_rmsnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                          bf16* __restrict__ out, int rows, int C, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
   const bf16* xr = x + (size_t)row * C;
   float ss = 0.f;
-  for (int c = lane * 8; c < C; c += 512) {
+  for (int c = threadIdx.x * 8; c < C; c += 2048) {
     bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
   }
-  ss = wave_sum(ss);
+  ss = t5_block_sum(ss, sh);
   const float r = rsqrtf(ss / (float)C + eps);
   bf16* orow = out + (size_t)row * C;
-  for (int c = lane * 8; c < C; c += 512) {
+  for (int c = threadIdx.x * 8; c < C; c += 2048) {
     bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
     bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c);
     bf16x8 o;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void t5_attn_kernel(const bf16* __restrict__ q
 extern "C" int ll_t5_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, float eps, ll_stream stream) {
   LL_REQUIRE(C > 0 && C % 8 == 0, "ll_t5_rmsnorm: C=%d must be a multiple of 8", C);
   if (rows == 0) return LL_OK;
-  hipLaunchKernelGGL(t5_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)w,
+  hipLaunchKernelGGL(t5_rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)w,
                      (bf16*)out, rows, C, eps);
   return ll_check_launch("ll_t5_rmsnorm");
 }
