@@ -20,8 +20,10 @@ def ops():
     return o
 
 
-def hn(name, shape, scale=1.0, shift=0.0, seed=101):
-    return (synth.hash_normal(seed, name, shape) * scale + shift).to(bf)
+def hn(name, shape, scale=1.0, shift=0.0, seed=101, device="cpu"):
+    """bf16 test data from the integer counter hash (bit-identical on the host and on the device: tests whose inputs only ever
+    live on the GPU generate them there -- the host takes seconds per 40 M elements)."""
+    return (synth.hash_normal(seed, name, shape, device=device) * scale + shift).to(bf)
 
 
 @pytest.mark.parametrize("C,F,fs,B", [(1536, 3, 40, 1), (256, 2, 24, 2), (1536, 1, 7, 2)])
@@ -417,13 +419,13 @@ def test_int8_quantize_and_w8a8_gemm(ops):
 
 def test_fused_ln_quantisation_is_bit_identical_to_unfused(ops):
     C, F, fs, B = 1536, 3, 40, 1
-    x = hn("x", (B, F * fs, C), 1.7, 0.3).to(DEV)
-    e = hn("e", (B, F, 6, C), 0.5).to(DEV)
-    mod = hn("mod", (6, C), 1 / math.sqrt(C)).to(DEV)
+    x = hn("x", (B, F * fs, C), 1.7, 0.3, device=DEV)
+    e = hn("e", (B, F, 6, C), 0.5, device=DEV)
+    mod = hn("mod", (6, C), 1 / math.sqrt(C), device=DEV)
     q1, s1 = ops.ln_modulate_q8(x, e, mod, 0, 1, F, 1e-6)
     q2, s2 = ops.quantize_rows(ops.ln_modulate(x, e, mod, 0, 1, F, 1e-6))
     assert torch.equal(q1, q2) and torch.equal(s1, s2)
-    w, b = hn("w", (C,), 0.1, 1.0).to(DEV), hn("b", (C,), 0.1).to(DEV)
+    w, b = hn("w", (C,), 0.1, 1.0, device=DEV), hn("b", (C,), 0.1, device=DEV)
     q1, s1 = ops.layernorm_affine_q8(x, w, b, 1e-6)
     q2, s2 = ops.quantize_rows(ops.layernorm_affine(x, w, b, 1e-6))
     assert torch.equal(q1, q2) and torch.equal(s1, s2)
@@ -433,9 +435,9 @@ def test_modulation_table_paths_are_bit_identical(ops):
     """`modulation + e` evaluated once per (layer, frame) by ll_modulation_table and handed to ln_modulate / the gate-residual
     GEMM epilogue with mod=None gives the bits of the per-row evaluation (same bf16 rounding points)."""
     B, F, fs, C, NL = 2, 3, 24, 256, 3
-    x = hn("mx", (B, F * fs, C), 1.7, 0.3).to(DEV)
-    e = hn("me", (B, F, 6, C), 0.5).to(DEV)
-    mods = hn("mmods", (NL, 6, C), 0.1).to(DEV)
+    x = hn("mx", (B, F * fs, C), 1.7, 0.3, device=DEV)
+    e = hn("me", (B, F, 6, C), 0.5, device=DEV)
+    mods = hn("mmods", (NL, 6, C), 0.1, device=DEV)
     tab = ops.modulation_table(e, mods)
     assert tab.shape == (NL, B, F, 6, C)
     assert torch.equal(tab.cpu(), (mods.cpu().view(NL, 1, 1, 6, C) + e.cpu().unsqueeze(0)).to(bf))
@@ -447,8 +449,8 @@ def test_modulation_table_paths_are_bit_identical(ops):
         qa, sa = ops.ln_modulate_q8(x, e, mods[l], 0, 1, F, 1e-6)
         qb, sb = ops.ln_modulate_q8(x, tab[l], None, 0, 1, F, 1e-6)
         assert torch.equal(qa, qb) and torch.equal(sa, sb)
-    h = hn("mh", (B, F * fs, 512)).to(DEV)
-    w, bias, res = hn("mw", (C, 512), 1 / 22).to(DEV), hn("mb", (C,), 0.1).to(DEV), hn("mres", (B, F * fs, C)).to(DEV)
+    h = hn("mh", (B, F * fs, 512), device=DEV)
+    w, bias, res = hn("mw", (C, 512), 1 / 22, device=DEV), hn("mb", (C,), 0.1, device=DEV), hn("mres", (B, F * fs, C), device=DEV)
     a = ops.gemm(h, w, bias, ops.EPI_BIAS_GATE_RES, res=res, e=e, mod=mods[1], gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
     b = ops.gemm(h, w, bias, ops.EPI_BIAS_GATE_RES, res=res, e=tab[1], mod=None, gate_idx=5, rows_per_batch=F * fs, frame_len=fs)
     assert torch.equal(a, b)
@@ -469,13 +471,13 @@ def test_qkv_projection_with_v_insert_is_bit_identical(ops, B, F, hp, wp, H, K, 
     C = H * D
     fs, L = hp * wp, F * hp * wp
     S = ws + wl + 11
-    x = hn("vx", (B, L, K)).to(DEV)
-    w, b = hn("vw", (3 * C, K), 1 / math.sqrt(K)).to(DEV), hn("vb", (3 * C,), 0.1).to(DEV)
-    wq, wk = hn("wq", (C,), 0.1, 1.0).to(DEV), hn("wk", (C,), 0.1, 1.0).to(DEV)
+    x = hn("vx", (B, L, K), device=DEV)
+    w, b = hn("vw", (3 * C, K), 1 / math.sqrt(K), device=DEV), hn("vb", (3 * C,), 0.1, device=DEV)
+    wq, wk = hn("wq", (C,), 0.1, 1.0, device=DEV), hn("wk", (C,), 0.1, 1.0, device=DEV)
     from longlive_amd.model import CausalWanModelHIP
     m = CausalWanModelHIP(synth.toy_config(num_layers=1), device=DEV)
     rope_f, rope_hw = m._rope_tables(hp, wp, DEV)
-    ck0, cv0 = hn("ck", (B, S, H, D)).to(DEV), hn("cv", (B, S, H, D)).to(DEV)
+    ck0, cv0 = hn("ck", (B, S, H, D), device=DEV), hn("cv", (B, S, H, D), device=DEV)
 
     def run(fused, int8):
         ck, cv = ck0.clone(), cv0.clone()
@@ -527,16 +529,16 @@ def test_gemm_splitk_matches_unsplit(ops, M, N, K, epi, splitk_kernel):
     ll_gemm_bf16: same products, the fp32 sum split once more -> <= 1 bf16 ulp apart; 30 repeated launches are bit-identical
     (a stale or torn hand-off would show up as a run-to-run difference) and leave the workspace's error word at zero."""
     from longlive_amd import _lib
-    x = hn("skx", (M, K)).to(DEV)
-    w = (hn("skw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("skb", (N,), 0.1).to(DEV)
+    x = hn("skx", (M, K), device=DEV)
+    w = (hn("skw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("skb", (N,), 0.1, device=DEV)
     kw = {}
     code = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "gate": ops.EPI_BIAS_GATE_RES, "res": ops.EPI_BIAS_RES}[epi]
     if epi in ("gate", "res"):
-        kw["res"] = hn("skr", (M, N)).to(DEV)
+        kw["res"] = hn("skr", (M, N), device=DEV)
     if epi == "gate":
         F_ = 3
-        kw.update(e=hn("ske", (1, F_, 6, N), 0.5).to(DEV), mod=hn("skm", (6, N), 0.1).to(DEV), gate_idx=5, rows_per_batch=M,
+        kw.update(e=hn("ske", (1, F_, 6, N), 0.5, device=DEV), mod=hn("skm", (6, N), 0.1, device=DEV), gate_idx=5, rows_per_batch=M,
                   frame_len=M // F_)
     want = ops.gemm(x, w, b, code, **kw)
     eligible = _lib.load().ll_gemm_splitk_plan(M, N, K, 0) == 1
@@ -565,16 +567,16 @@ def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
     """The generated one-wave-per-SIMD GEMM kernels (tuning key gemm_asm; gen/gemm_asm_gen.py) against the HIP kernels they replace,
     at the block linears' shapes (FFN1, O / cross-o / cross-q, FFN2, B = 2) and at ragged edges: same products, the fp32 sum taken in
     another order -> <= 1-2 bf16 ulp apart (absolute bound where a residual cancels), and against fp64."""
-    x = hn("gx", (M, K)).to(DEV)
-    w = (hn("gw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("gb", (N,), 0.1).to(DEV)
+    x = hn("gx", (M, K), device=DEV)
+    w = (hn("gw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("gb", (N,), 0.1, device=DEV)
     kw = {}
     code = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "gate": ops.EPI_BIAS_GATE_RES, "res": ops.EPI_BIAS_RES}[epi]
     if epi in ("gate", "res"):
-        kw["res"] = hn("gr", (M, N)).to(DEV)
+        kw["res"] = hn("gr", (M, N), device=DEV)
     if epi == "gate":
         F_ = 3 if M % 3 == 0 else 1
-        kw.update(e=hn("ge", (1, F_, 6, N), 0.5).to(DEV), mod=None, gate_idx=5, rows_per_batch=M, frame_len=M // F_)
+        kw.update(e=hn("ge", (1, F_, 6, N), 0.5, device=DEV), mod=None, gate_idx=5, rows_per_batch=M, frame_len=M // F_)
     from longlive_amd import _lib
     import ctypes as C
     buf = C.create_string_buffer(256)
@@ -608,10 +610,10 @@ def test_gemm_small_m_split_k_matches_plain(ops, M, N, K, epi):
     lib = _lib.load()
     S = lib.ll_gemm_ksplit_plan(M, N, K)
     assert S >= 2, (M, N, K, S)
-    x = hn("kx", (M, K)).to(DEV)
-    w = (hn("kw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("kb", (N,), 0.1).to(DEV)
-    kw = {"res": hn("kr", (M, N)).to(DEV)} if epi == "res" else {}
+    x = hn("kx", (M, K), device=DEV)
+    w = (hn("kw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("kb", (N,), 0.1, device=DEV)
+    kw = {"res": hn("kr", (M, N), device=DEV)} if epi == "res" else {}
     code = ops.EPI_BIAS_RES if epi == "res" else ops.EPI_BIAS
     got = ops.gemm(x, w, b, code, **kw)
     again = ops.gemm(x, w, b, code, **kw)
@@ -635,9 +637,9 @@ def test_gemm_small_m_split_k_is_batch_invariant(ops):
     lib = _lib.load()
     N, K = 1536, 1536
     assert lib.ll_gemm_ksplit_plan(512, N, K) == lib.ll_gemm_ksplit_plan(1024, N, K) >= 2
-    x = hn("bx", (1024, K)).to(DEV)
-    w = (hn("bw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("bb", (N,), 0.1).to(DEV)
+    x = hn("bx", (1024, K), device=DEV)
+    w = (hn("bw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("bb", (N,), 0.1, device=DEV)
     both = ops.gemm(x, w, b)
     for i in (0, 1):
         assert torch.equal(both[512 * i:512 * (i + 1)], ops.gemm(x[512 * i:512 * (i + 1)].contiguous(), w, b))
@@ -647,11 +649,11 @@ def test_gemm_small_m_split_k_is_batch_invariant(ops):
 def test_gemm_residual_t5norm_is_the_two_kernels(ops, M, N, K):
     """ll_gemm_bf16_ksplit_t5norm: x_new = res + linear(x), h = T5LayerNorm(x_new) in one pass over the rows on the small-M path --
     both outputs bit-identical to ops.gemm(EPI_BIAS_RES) + ops.t5_rmsnorm (the fused pass keeps their order of operations)."""
-    x = hn("tx", (M, K)).to(DEV)
-    w = (hn("tw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("tb", (N,), 0.1).to(DEV)
-    res = hn("tr", (M, N)).to(DEV)
-    nw = hn("tn", (N,), 0.2, 1.0).to(DEV)
+    x = hn("tx", (M, K), device=DEV)
+    w = (hn("tw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("tb", (N,), 0.1, device=DEV)
+    res = hn("tr", (M, N), device=DEV)
+    nw = hn("tn", (N,), 0.2, 1.0, device=DEV)
     want_x = ops.gemm(x, w, b, ops.EPI_BIAS_RES, res=res)
     want_h = ops.t5_rmsnorm(want_x, nw)
     got_x, got_h = ops.gemm_res_t5norm(x, w, b, res, nw)
@@ -663,9 +665,9 @@ def test_gemm_splitk_handoff_is_fresh_across_launches(ops, splitk_kernel):
     """The partial tiles live at fixed workspace addresses: alternate two different activations so that a partner reading the
     PREVIOUS launch's bytes (a stale line somewhere between the two workgroups) cannot reproduce the right answer."""
     M, N, K = 4680, 1536, 8960
-    w = (hn("fw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("fb", (N,), 0.1).to(DEV)
-    xs = [hn(f"fx{i}", (M, K)).to(DEV) for i in range(2)]
+    w = (hn("fw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("fb", (N,), 0.1, device=DEV)
+    xs = [hn(f"fx{i}", (M, K), device=DEV) for i in range(2)]
     want = [ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True) for x in xs]
     torch.cuda.synchronize()
     assert not torch.equal(want[0], want[1])
@@ -693,9 +695,9 @@ def test_gemm_splitk_handoff_is_fail_safe(ops, splitk_kernel):
     from longlive_amd import _lib
     lib = _lib.load()
     M, N, K = 4680, 1536, 8960
-    w = (hn("zw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("zb", (N,), 0.1).to(DEV)
-    x, x2 = hn("zx", (M, K)).to(DEV), hn("zx2", (M, K)).to(DEV)
+    w = (hn("zw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("zb", (N,), 0.1, device=DEV)
+    x, x2 = hn("zx", (M, K), device=DEV), hn("zx2", (M, K), device=DEV)
     want = ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True)
     ws = ops.splitk_workspace(x.device, M, N)
     ws[:4092].view(torch.int32).fill_(0x5a5a5a5a)        # every flag word poisoned; the error word (last of the page) stays 0
@@ -724,9 +726,9 @@ def test_gemm_splitk_l2_exchange_matches(ops, splitk_kernel):
     partners do not share an XCD): same bits as the shipped exchange."""
     from longlive_amd import _lib
     M, N, K = 4680, 1536, 8960
-    w = (hn("lw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("lb", (N,), 0.1).to(DEV)
-    xs = [hn(f"lx{i}", (M, K)).to(DEV) for i in range(2)]
+    w = (hn("lw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("lb", (N,), 0.1, device=DEV)
+    xs = [hn(f"lx{i}", (M, K), device=DEV) for i in range(2)]
     want = [ops.gemm(x, w, b, ops.EPI_BIAS, splitk=True) for x in xs]
     try:
         assert _lib.load().ll_set_tuning(b"gemm_splitk_l2", 1) == 0
@@ -740,13 +742,13 @@ def test_gemm_splitk_l2_exchange_matches(ops, splitk_kernel):
 def test_gemm_w8a8_splitk_is_exact(ops):
     """W8A8 split-K: the halves exchange int32 sums, so the result equals the unsplit kernel's bit for bit."""
     M, N, K = 4680, 1536, 8960
-    x = hn("qx", (M, K)).to(DEV)
-    w = (hn("qw", (N, K)) / math.sqrt(K)).to(bf).to(DEV)
-    b = hn("qb", (N,), 0.1).to(DEV)
+    x = hn("qx", (M, K), device=DEV)
+    w = (hn("qw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("qb", (N,), 0.1, device=DEV)
     xq, sx = ops.quantize_rows(x)
     wq, sw = ops.quantize_rows(w)
-    res = hn("qr", (M, N)).to(DEV)
-    kw = dict(res=res, e=hn("qe", (1, 3, 6, N), 0.5).to(DEV), mod=hn("qm", (6, N), 0.1).to(DEV), gate_idx=5, rows_per_batch=M,
+    res = hn("qr", (M, N), device=DEV)
+    kw = dict(res=res, e=hn("qe", (1, 3, 6, N), 0.5, device=DEV), mod=hn("qm", (6, N), 0.1, device=DEV), gate_idx=5, rows_per_batch=M,
               frame_len=M // 3)
     want = ops.gemm_w8a8(xq, sx, wq, sw, b, ops.EPI_BIAS_GATE_RES, **kw)
     for _ in range(10):
