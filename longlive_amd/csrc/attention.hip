@@ -1223,7 +1223,10 @@ int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out
 static int g_attn_asm_min_keys = 8 * KT;    // the generated kernel from 512 keys on (cross-attention: 22.7 vs 26.8 us, profiles/r03_cross_attn_asm.txt)
 void ll_set_attn_asm_min_internal(int v) { g_attn_asm_min_keys = v; }
 static bool attn_asm_eligible(int nkeys, int ldk) {
-  return g_attn_asm && g_attn_variant >= 2 && nkeys >= g_attn_asm_min_keys && (long long)nkeys * ldk * 2 < 0x7fffffffLL;
+  // (the generated kernel needs at least two key tiles: its first tile is a special case and so is its last; whatever the tuning
+  //  key says, shorter ranges stay on the HIP kernels -- tests/test_attn_asm_emu.py::test_two_tiles_is_the_shortest_range)
+  const int min_keys = g_attn_asm_min_keys > 2 * KT ? g_attn_asm_min_keys : 2 * KT;
+  return g_attn_asm && g_attn_variant >= 2 && nkeys >= min_keys && (long long)nkeys * ldk * 2 < 0x7fffffffLL;
 }
 static int g_attn_mfma16 = 0;     // tuning key attn_mfma16: 1 = the ping-pong loop on v_mfma_f32_16x16x32_bf16 (flash_attn_pipe16_kernel)
 void ll_set_attn_mfma16_internal(int v) { g_attn_mfma16 = v; }

@@ -116,3 +116,13 @@ def test_rescale_path_is_taken_and_exact(kernel_text):
     out, ref, steps, m = run_case(kernel_text, "lazy", rows_valid=256, nkeys=7 * 64, seed=5, spikes=spikes)
     err = np.abs(out - ref).max()
     assert np.isfinite(out).all() and err < 2e-2, err
+
+
+@pytest.mark.parametrize("nkeys,mode", [(65, "lazy"), (100, "mixed"), (128, "eager"), (3 * 64 + 1, "mixed")])
+def test_two_tiles_is_the_shortest_range(kernel_text, nkeys, mode):
+    """The launcher never sends fewer than two key tiles (attention.hip: attn_asm_eligible): the first tile and the last tile are
+    both special cases of the generated text and a single tile would have to be both.  Two tiles, ragged or full, must work; the
+    third completion model (LDS-DMA lands at once, LDS reads late) is exercised here as well."""
+    out, ref, steps, m = run_case(kernel_text, mode, rows_valid=200, nkeys=nkeys, seed=2, kstart=5)
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < 1.2e-2, err

@@ -130,6 +130,31 @@ def test_gemm_asm_partial_sums_for_split_k():
     assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+def test_gemm_asm_random_geometries():
+    """Seeded sweep over tile widths, epilogues, ragged row counts, K lengths, frame lengths and row windows (the gate-row read past
+    M of round 3 was a geometry nobody had written down: small frames under a ragged last tile)."""
+    rng = np.random.default_rng(20261004)
+    for _ in range(8):
+        WN = int(rng.choice([128, 128, 192, 224, 256]))
+        epi = int(rng.choice([G.EPI_BIAS, G.EPI_GELU, G.EPI_GATE_RES, G.EPI_RES, G.EPI_PARTIAL]))
+        rows = int(rng.integers(1, 257))
+        K = 64 * int(rng.integers(4, 10))
+        flen = int(rng.integers(1, 200))
+        m0 = int(rng.integers(0, 5)) * 256
+        lo = int(rng.integers(0, rows)) if (epi == G.EPI_BIAS and rng.random() < 0.5) else 0
+        mode = str(rng.choice(["lazy", "eager", "mixed"]))
+        got, want = run_case(WN, epi, mode, rows_valid=rows, K=K, seed=int(rng.integers(1 << 30)), m0=m0, frame_len=flen, row_lo=lo)
+        tag = (WN, epi, rows, K, flen, m0, lo, mode)
+        if lo:
+            assert np.isnan(got[:lo]).all(), tag
+        g, w = got[lo:], want[lo:]
+        assert np.isfinite(g).all(), tag
+        if epi == G.EPI_PARTIAL:
+            assert np.abs(g - w).max() < 2e-5 * max(1.0, np.abs(w).max()), tag
+        else:
+            assert (g == w).mean() > 0.93 and np.abs(g - w).max() < 0.13, (tag, (g == w).mean(), np.abs(g - w).max())
+
+
 def test_gemm_asm_text_assembles(tmp_path):
     clang = "/opt/rocm/lib/llvm/bin/clang"
     if not os.path.exists(clang):
