@@ -126,3 +126,20 @@ def test_two_tiles_is_the_shortest_range(kernel_text, nkeys, mode):
     out, ref, steps, m = run_case(kernel_text, mode, rows_valid=200, nkeys=nkeys, seed=2, kstart=5)
     err = np.abs(out - ref).max()
     assert np.isfinite(out).all() and err < 1.2e-2, err
+
+
+def test_random_geometries(kernel_text):
+    """Seeded sweep: row counts around the wave / q-block edges, 2-12 key tiles with every kind of last tile, key ranges that start
+    anywhere in the cache, spiked keys that force the rescale path, all three completion models."""
+    rng = np.random.default_rng(20261004)
+    for it in range(8):
+        rows = int(rng.choice([1, 8, 33, 64, 65, 72, 129, 200, 255, 256]))
+        nt = int(rng.integers(2, 13))
+        nkeys = 64 * (nt - 1) + int(rng.choice([1, 31, 32, 33, 64, int(rng.integers(1, 65))]))
+        spikes = [(int(rng.integers(0, rows)), int(rng.integers(0, nkeys)), float(rng.choice([2.5, 4.0, 6.0])))
+                  for _ in range(int(rng.integers(0, 4)))]
+        mode = str(rng.choice(["lazy", "eager", "mixed"]))
+        out, ref, steps, m = run_case(kernel_text, mode, rows_valid=rows, nkeys=nkeys, seed=300 + it, spikes=spikes,
+                                      kstart=int(rng.integers(0, 70)))
+        err = np.abs(out - ref).max()
+        assert np.isfinite(out).all() and err < 2.5e-2, (rows, nkeys, mode, spikes, err)
