@@ -28,7 +28,7 @@ def rbf(x):
     return f32(bf(x))
 
 
-def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130, row_lo=0):
+def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130, row_lo=0, xpad=0, ypad=0):
     rng = np.random.default_rng(seed)
     text = G.generate(WN, epi, f"T{WN}E{epi}")
     assert G.lint(text) == []
@@ -40,16 +40,19 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
     nframes = (m0 + rows_valid - 1) // frame_len + 1      # exactly the frames the valid rows touch: rows past M must not index beyond them
     gate = bf(0.5 * rng.standard_normal((nframes, N)))
     mem = E.Memory()
-    ax, aw, ab, ar, ag = mem.alloc(x), mem.alloc(w), mem.alloc(bias), mem.alloc(res), mem.alloc(gate)
     partial = epi == G.EPI_PARTIAL
-    ay = mem.alloc(np.full((rows_valid, N), np.nan, dtype=np.float32) if partial else np.full((rows_valid, N), 0x7FC0, dtype=np.uint16))
+    # row strides larger than the row (ldx > K, ldo > N: column slices of wider tensors); the padding holds NaN patterns
+    xs = np.full((rows_valid, K + xpad), 0x7FC0, dtype=np.uint16); xs[:, :K] = x
+    rs = np.full((rows_valid, N + ypad), 0x7FC0, dtype=np.uint16); rs[:, :N] = res
+    ax, aw, ab, ar, ag = mem.alloc(xs), mem.alloc(w), mem.alloc(bias), mem.alloc(rs), mem.alloc(gate)
+    ay = mem.alloc(np.full((rows_valid, N + ypad), np.nan, dtype=np.float32) if partial else np.full((rows_valid, N + ypad), 0x7FC0, dtype=np.uint16))
     m = E.Machine(text, mem, 4, mode=mode, lds_bytes=G.Cfg(WN, epi).lds_bytes)
     for wv in m.waves:
         s = wv.s
         def put64(i, val):
             s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
         put64(G.S_X, ax); put64(G.S_W, aw); put64(G.S_Y, ay); put64(G.S_BIAS, ab); put64(G.S_RES, ar); put64(G.S_GATE, ag)
-        s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K * 2, K * 2, N * (4 if partial else 2)
+        s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = (K + xpad) * 2, K * 2, (N + ypad) * (4 if partial else 2)
         s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 64
         s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
         s[G.S_ROWLO] = row_lo
@@ -59,8 +62,12 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
     m.run()
     acc = (f32(x).astype(np.float64) @ f32(w).astype(np.float64).T).astype(np.float32)
     if partial:                                       # one K-range of a split-K call: the fp32 accumulators as they stand
-        return mem.get(ay).view(np.float32).reshape(rows_valid, N).astype(np.float64), acc.astype(np.float64)
-    got = f32(mem.get(ay).view(np.uint16).reshape(rows_valid, N)).astype(np.float64)
+        yfull = mem.get(ay).view(np.float32).reshape(rows_valid, N + ypad)
+        assert np.isnan(yfull[:, N:]).all(), "the kernel wrote past its N columns"
+        return yfull[:, :N].astype(np.float64), acc.astype(np.float64)
+    yfull = mem.get(ay).view(np.uint16).reshape(rows_valid, N + ypad)
+    assert (yfull[:, N:] == 0x7FC0).all(), "the kernel wrote past its N columns"
+    got = f32(yfull[:, :N]).astype(np.float64)
     v = rbf(acc + f32(bias)[None, :])
     if epi == G.EPI_BIAS:
         want = v
@@ -128,6 +135,14 @@ def test_gemm_asm_partial_sums_for_split_k():
     """EPI_PARTIAL: the kernel of the small-M split-K path stores its fp32 accumulators (rows past M untouched)."""
     got, want = run_case(128, G.EPI_PARTIAL, "lazy", rows_valid=100, K=512)
     assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_gemm_asm_row_strides_wider_than_the_rows():
+    """ldx > K and ldo > N (the ABI lets X / Y / RES be column slices of wider tensors): nothing outside the slice is read into
+    the result or written."""
+    for epi in (G.EPI_GATE_RES, G.EPI_GELU):
+        got, want = run_case(128 if epi == G.EPI_GATE_RES else 224, epi, "lazy", rows_valid=150, K=320, xpad=24, ypad=40)
+        assert np.isfinite(got).all() and (got == want).mean() > 0.95 and np.abs(got - want).max() < 0.07
 
 
 def test_gemm_asm_random_geometries():
