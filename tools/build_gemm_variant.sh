@@ -1,9 +1,19 @@
 #!/bin/bash
-# tools/build_gemm_variant.sh NAME VAR=1 ... : timing-only build of the generated GEMM kernels into experiments/r03/libs/NAME
+# tools/build_gemm_variant.sh NAME VAR=1 ... : timing-only build of the generated GEMM kernels (ASM_G_NO_* switches: results INVALID)
+# into experiments/r03/libs/NAME/liblonglive_hip.so (run a tool against it with LD_LIBRARY_PATH=experiments/r03/libs/NAME).
+# The in-tree library is rebuilt WITHOUT the switches before the script returns, whatever happens in between.
 set -e
 cd /root/repo
 name=$1; shift
-rm -f /root/repo/longlive_amd/csrc/build/gemm_asm_192_0.inc /root/repo/longlive_amd/csrc/build/gemm_asm_128_0.inc /root/repo/longlive_amd/csrc/build/gemm_asm_128_2.inc /root/repo/longlive_amd/csrc/build/gemm_asm_128_3.inc /root/repo/longlive_amd/csrc/build/gemm_asm_224_1.inc /root/repo/longlive_amd/csrc/build/gemm_asm.o
-env "$@" make -C /root/repo/longlive_amd/csrc -j6 2>&1 | grep -E " error|lint findings" | grep -v " 0 lint" || true
-mkdir -p /root/repo/experiments/r03/libs/$name
-cp /root/repo/longlive_amd/liblonglive_hip.so /root/repo/experiments/r03/libs/$name/liblonglive_hip.so
+clean() {
+  rm -f longlive_amd/csrc/build/gemm_asm_*.inc longlive_amd/csrc/build/gemm_asm.o
+}
+restore() {
+  clean
+  env -u ASM_G_NO_MFMA -u ASM_G_NO_X -u ASM_G_NO_W -u ASM_G_NO_WREAD -u ASM_G_NO_EPI make -C longlive_amd/csrc -j6 > /dev/null 2>&1 || echo "WARNING: could not rebuild the in-tree library"
+}
+trap restore EXIT
+clean
+env "$@" make -C longlive_amd/csrc -j6 2>&1 | grep -E " error|lint findings" | grep -v " 0 lint" || true
+mkdir -p experiments/r03/libs/$name
+cp longlive_amd/liblonglive_hip.so experiments/r03/libs/$name/liblonglive_hip.so
