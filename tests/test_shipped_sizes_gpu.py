@@ -224,10 +224,21 @@ def test_real_shape_recache_vs_reference(gs):
 
 
 @pytest.mark.skipif(not _have("real_block.pt"), reason="golden missing")
-def test_real_shape_block_vs_reference():
+@pytest.mark.parametrize("kernels", ["generated", "hip"])
+def test_real_shape_block_vs_reference(kernels):
     """ONE CausalWanAttentionBlock at the real shape in steady state (full 18720-slot cache: roll + insert, Lk = 18720)
     against the reference block's CPU output (oracle/make_golden.py::gen_real_block): 48 sampled output rows, 64 sampled
-    cache slots, end indices -- a per-block bound that a 30-layer rel-L2 cannot hide a wrong tile under."""
+    cache slots, end indices -- a per-block bound that a 30-layer rel-L2 cannot hide a wrong tile under.  Both kernel families
+    are held to it: the shipped generated set (flash_attn_asm_kernel, gemm_asm_*) and the HIP set it replaced."""
+    if kernels == "hip":
+        _tuning("gemm_asm", 0); _tuning("attn_asm", 0)
+    try:
+        _real_shape_block(kernels)
+    finally:
+        _tuning("gemm_asm", 3); _tuning("attn_asm", 1)
+
+
+def _real_shape_block(kernels):
     from longlive_amd.model import CausalWanModelHIP, _kv_commit
     rec = load_golden("real_block.pt")
     cfg = synth.longlive_1_3b(num_layers=1)
@@ -248,7 +259,7 @@ def test_real_shape_block_vs_reference():
     _kv_commit(kv, plan.G_new, plan.E_new)
     y = xs[0, rec["rows"].to(DEV)].cpu()
     r, c = rel_l2(y, rec["y_rows"]), cosine(y, rec["y_rows"])
-    print(f"real block: relL2 {r:.2e} cos {c:.6f}")
+    print(f"real block ({kernels} kernels): relL2 {r:.2e} cos {c:.6f}")
     assert r < 6e-3 and c > 0.9999, (r, c)
     assert (kv["global_end_index"], kv["local_end_index"]) == tuple(rec["idx"])
     sl = rec["slots"].to(DEV)
