@@ -50,8 +50,8 @@ const char* ll_last_error(void);
  * (default 4; <= 1: N fastest);  "attn_asm" 1 (default) = the generated one-wave-per-SIMD self-attention kernel
  * (flash_attn_asm_kernel) for single key ranges of >= "attn_asm_min_keys" keys (default 512: self- and cross-attention), 0 = the HIP kernels;  "gemm_asm" bit 0 = the generated GEMM kernels
  * (gemm_asm_224_gelu: FFN1; gemm_asm_192_bias: QKV with its V-cache redirect; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual) where they cover the call,
- * bit 1 = also in place of the split-K kernel, bits 2 / 3 = leave the GELU / the 128-wide kernels out (default 3; 0 = HIP
- * kernels only);  "attn_mfma16" 1 = 16x16x32 MFMA variant of the HIP attention kernel (measured slower; A/B only);
+ * bit 1 = also in place of the split-K kernel, bits 2 / 3 = leave the GELU / the 128-wide kernels out, bit 4 (16) = ll_gemm_w8a8 /
+ * ll_gemm_w8a8_qkv on the generated W8A8 kernels too (bit-identical results; default 3; 0 = HIP kernels only);  "attn_mfma16" 1 = 16x16x32 MFMA variant of the HIP attention kernel (measured slower; A/B only);
  * "gemm_splitk_fault" 1 = test hook: the split-K partner never signals (exercises the bounded wait).
  * Unknown key: LL_ERR_INVALID_ARG. */
 int ll_set_tuning(const char* key, int value);

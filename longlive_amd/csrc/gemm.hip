@@ -868,6 +868,8 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
                     int gm, hipStream_t s);
 int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool has_v, bool v_ok, int frame_len);
 int gemm_ksplit_splits(int M, int N, int K, int cus);
+int gemm_asm_launch_i8(const int8_t* x, const int8_t* w, bf16* out, int M, int N, int K, int ldo, int epilogue, const EpiArgs& ea,
+                       int gm, hipStream_t s);
 int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, int M, int N, int K, int ldx, int ldo,
                            int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s, const bf16* norm_w,
                            float eps, bf16* h_out);
@@ -884,6 +886,9 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
   // GELU (256 x 224) / the 128-wide kernels out (A/B of their share in the pipeline's power budget)
   if (!I8 && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2 &&
       gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s))
+    return 0;
+  if (I8 && (g_gemm_asm & 16) && gemm_asm_wanted(epilogue) && xrow_bytes == (size_t)K && wrow_bytes == (size_t)K &&      // bit 4: W8A8 on the generated kernels
+      gemm_asm_launch_i8((const int8_t*)x, (const int8_t*)w, out, M, N, K, ldo, epilogue, ea, g_gemm_group_m, s))
     return 0;
   const int kbytes = I8 ? K : 2 * K;
   const int nk = kbytes / ROWB;

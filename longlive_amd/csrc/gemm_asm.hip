@@ -57,6 +57,52 @@
 #undef GA_WN
 #undef GA_INC
 
+#define GA_NAME gemm_asmq_224_gelu
+#define GA_WN 224
+#define GA_INC "build/gemm_asmq_224_1.inc"
+#define GA_I8 1
+#include "gemm_asm_kernel.inl"
+#undef GA_I8
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asmq_192_bias
+#define GA_WN 192
+#define GA_INC "build/gemm_asmq_192_0.inc"
+#define GA_I8 1
+#include "gemm_asm_kernel.inl"
+#undef GA_I8
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asmq_128_bias
+#define GA_WN 128
+#define GA_INC "build/gemm_asmq_128_0.inc"
+#define GA_I8 1
+#include "gemm_asm_kernel.inl"
+#undef GA_I8
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asmq_128_gate_res
+#define GA_WN 128
+#define GA_INC "build/gemm_asmq_128_2.inc"
+#define GA_I8 1
+#include "gemm_asm_kernel.inl"
+#undef GA_I8
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+#define GA_NAME gemm_asmq_128_res
+#define GA_WN 128
+#define GA_INC "build/gemm_asmq_128_3.inc"
+#define GA_I8 1
+#include "gemm_asm_kernel.inl"
+#undef GA_I8
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+
 // tile width of the generated kernel that covers this call, 0 = none (the caller takes the HIP kernels).
 // plain = no int8 scales, no per-batch modulation vector; v_ok = no V-cache output, or one the 192-wide kernel can redirect per
 // tile (one batch element, the V third starting on a tile boundary)
@@ -235,5 +281,41 @@ int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16*
     hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS_RES>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);
   else
     hipLaunchKernelGGL((gemm_ksplit_reduce_kernel<LL_EPI_BIAS>), grid, block, 0, s, (const float*)workspace, splits, M, N, bias, res, out, ldo);
+  return 1;
+}
+
+// W8A8 form of gemm_asm_launch (ll_gemm_w8a8 / ll_gemm_w8a8_qkv): int8 operands with row strides K, fp32 scales sx [M] / sw [N];
+// the same tile widths, epilogues and V-cache redirect.  Integer sums are exact and the epilogue applies gemm_common.h's operations
+// in its order, so the results are bit-identical to the HIP W8A8 kernels.  1 = launched, 0 = not covered.
+int gemm_asm_launch_i8(const int8_t* x, const int8_t* w, bf16* out, int M, int N, int K, int ldo, int epilogue, const EpiArgs& ea,
+                       int gm, hipStream_t s) {
+  if (ea.sx == nullptr || ea.sw == nullptr || ea.mod != nullptr || M <= 0 || K % 128 != 0 || K < 512) return 0;
+  if (epilogue == LL_EPI_BIAS_GATE_RES && ea.frame_len <= 0) return 0;
+  if ((long long)256 * K >= 0x7fffffffLL) return 0;
+  const bool has_v = ea.v_out != nullptr;
+  int wn = 0;
+  if (has_v) wn = (ea.v_L == M && ea.v_col0 % 192 == 0 && ea.v_C > 0 && epilogue == LL_EPI_BIAS && N % 192 == 0) ? 192 : 0;
+  else if (epilogue == LL_EPI_BIAS_GELU) wn = N % 224 == 0 ? 224 : 0;
+  else if (epilogue == LL_EPI_BIAS && N > 2048 && N % 192 == 0) wn = 192;
+  else if (N % 128 == 0 && N <= 2048) wn = 128;
+  if (!wn) return 0;
+  const void* fn = wn == 224 ? (const void*)gemm_asmq_224_gelu
+                   : wn == 192 ? (const void*)gemm_asmq_192_bias
+                   : epilogue == LL_EPI_BIAS ? (const void*)gemm_asmq_128_bias
+                   : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asmq_128_gate_res : (const void*)gemm_asmq_128_res;
+  static bool attr[4] = {false, false, false, false};
+  const int slot = wn == 224 ? 0 : wn == 192 ? 1 : epilogue == LL_EPI_BIAS ? 2 : 3;      // (gate_res / res share the 128-wide LDS size)
+  const int lds = 3 * wn * 128 + 4 * 2 * 8192;
+  if (!attr[slot] || slot == 3) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr[slot] = true; }
+  const int ntm = (M + 255) / 256, ntn = N / wn;
+  const bf16* gate = epilogue == LL_EPI_BIAS_GATE_RES ? ea.e + (size_t)ea.gate_idx * N : nullptr;
+  const int gstride = ea.nmod * N * 2;
+  bf16* v_out = ea.v_out;
+  int v_col0 = ea.v_col0, v_C = ea.v_C, v_shift = ea.v_write_start - ea.v_roped_offset, v_lo = ea.v_roped_offset,
+      v_hi = ea.v_roped_offset + ea.v_write_len, ldx = K;
+  void* args[] = {(void*)&x, (void*)&w, (void*)&ea.bias, (void*)&out, (void*)&ea.res, (void*)&gate, (void*)&M, (void*)&N, (void*)&K,
+                  (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm,
+                  (void*)&v_out, (void*)&v_col0, (void*)&v_C, (void*)&v_shift, (void*)&v_lo, (void*)&v_hi, (void*)&ea.sx, (void*)&ea.sw};
+  (void)hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s);
   return 1;
 }

@@ -44,6 +44,7 @@ S_LDX, S_LDW, S_LDO = 20, 21, 22                                  # row strides 
 S_ROWS, S_COLS, S_NK = 23, 24, 25                                 # valid rows (M - m0), valid columns (N - n0, >= WN on this path), K / 64
 S_FLEN, S_GSTRIDE, S_M0 = 26, 27, 28                              # gate: frame_len (rows per frame), bytes between frames' gate rows, m0
 S_ROWLO = 29                                                      # first row of the tile that is stored (0 except in V tiles of the fused QKV projection)
+S_SX, S_SW = 64, 66                                               # W8A8 kernels: 64-bit bases of the activation scales (sx + m0) and weight scales (sw + n0), fp32
 # working scalars
 S_XRS, S_WRS = 32, 36                                             # descriptors
 S_WAVE, S_I, S_T0, S_T1, S_T2 = 40, 41, 44, 45, 46
@@ -61,9 +62,10 @@ def KN(k):
 
 
 class Cfg:
-    def __init__(self, WN, epi):
+    def __init__(self, WN, epi, i8=False):
         assert WN % 32 == 0 and 64 <= WN <= 256
-        self.WN, self.NB, self.MB, self.epi = WN, WN // 32, 2, epi
+        assert not (i8 and epi == EPI_PARTIAL)
+        self.WN, self.NB, self.MB, self.epi, self.i8 = WN, WN // 32, 2, epi, i8
         self.nacc = self.MB * self.NB * 16
         self.slotb = WN * 128                                      # bytes of one W slot: WN rows x 128 B (a 64-deep K-step)
         self.npw = WN // 32                                        # 1-KiB LDS-DMA pieces of W per wave and K-step (WN / 8 pieces of 8 rows)
@@ -87,6 +89,10 @@ class Cfg:
         # first staging piece, so the epilogue starts without an exposed memory latency
         self.V_EA = nxt + 37                                      # +0,+1 row byte offsets in Y / RES; +2 bias column offset; +3,+4 gate row offsets
         top = self.V_EA + 5
+        if i8:                                                    # W8A8: +5 column byte offset into the weight scales (16 h); V_SX[mb] = (sx[row], sx[row]) pairs
+            self.V_SX = top + 2                                   # (register pairs start on even registers)
+            top += 6
+        assert top % 2 == 0, top
         self.nl = {EPI_GATE_RES: 6, EPI_RES: 2}.get(epi, 0)       # global reads per epilogue block
         self.V_E0 = top                                           # the first block's gate / residual pieces (16 registers) when nl
         top += 16 if self.nl else 0
@@ -110,7 +116,8 @@ def mfmas(c: Cfg, h):
         for nb in range(c.NB):
             for mb in range(c.MB):
                 a = areg(c.acc(mb, nb), 16)
-                out.append(f"v_mfma_f32_32x32x16_bf16 {a}, {vreg(c.fw(p, nb, ks), 4)}, {vreg(c.fx(b, mb, 2 * hf + ks), 4)}, {a}")
+                op = "v_mfma_i32_32x32x32_i8" if c.i8 else "v_mfma_f32_32x32x16_bf16"      # same operand registers: 16 B of K per lane and MFMA
+                out.append(f"{op} {a}, {vreg(c.fw(p, nb, ks), 4)}, {vreg(c.fx(b, mb, 2 * hf + ks), 4)}, {a}")
     return out
 
 
@@ -161,7 +168,7 @@ def drop_loads(ops):
     return [o for o in ops if not o.startswith("buffer_load")]
 
 
-def generate(WN: int, epi: int, prefix: str) -> str:
+def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
     """Issue order of the staging (one in-order vmcnt queue per wave): W(j) in half-step 2 j - 5, X(j) in half-step 2 j - 4, so at
     the END of the even half-step 2 s the wave has issued ... W(s+1) X(s+1) W(s+2) X(s+2): `s_waitcnt vmcnt(npw + 8)` there = the
     next K-step's operands have landed.  The one barrier per K-step stands right behind that wait: it makes W(s+1) visible (first
@@ -169,7 +176,7 @@ def generate(WN: int, epi: int, prefix: str) -> str:
     which the odd half-step then refills with W(s+3).  X needs no barrier: unit (s+1) % 2 is read into FX[(s+1) & 1] in the odd
     half-step of K-step s and refilled (X(s+3)) in the even half-step after it -- the reads are retired by the fragment waits of
     the W reads issued after them (LDS returns in order)."""
-    c = Cfg(WN, epi)
+    c = Cfg(WN, epi, i8)
     g = Gen()
     I = g.I
     T = 128                                            # setup scratch (below the address registers, inside the fragment file)
@@ -349,6 +356,15 @@ def gen_epilogue_setup(g: Gen, c: Cfg):
         I(f"v_cmp_lt_u32_e64 {sreg(S_MSK + 2 * mb, 2)}, {vreg(c.V_ROW + mb)}, {sreg(S_ROWS)}")
         I(f"v_cmp_ge_u32_e64 vcc, {vreg(c.V_ROW + mb)}, {sreg(S_ROWLO)}")
         I(f"s_and_b64 {sreg(S_MSK + 2 * mb, 2)}, {sreg(S_MSK + 2 * mb, 2)}, vcc")
+    if c.i8:
+        # W8A8: the lane's activation scale per row block (rows past M: the last valid row's, never stored) and the byte offset of
+        # its four weight-scale columns inside a 32-column block
+        I(f"v_lshlrev_b32 {vreg(EA + 5)}, 4, {vreg(c.V_H)}")
+        I(f"s_sub_u32 {sreg(S_T1)}, {sreg(S_ROWS)}, 1")
+        for mb in range(c.MB):
+            I(f"v_min_u32 {vreg(T + 48)}, {sreg(S_T1)}, {vreg(c.V_ROW + mb)}")
+            I(f"v_lshlrev_b32 {vreg(T + 48)}, 2, {vreg(T + 48)}")
+            I(f"global_load_dword {vreg(c.V_SX + 2 * mb)}, {vreg(T + 48)}, {sreg(S_SX, 2)}")
     # early reads
     for nb in range(c.early_nb):
         for g4 in range(4):
@@ -404,18 +420,45 @@ def gen_epilogue(g: Gen, c: Cfg):
     BB, PB = T + 72, T + 72 + 8 * c.NB                                       # late bias raw [nb][g4] (2 registers each); block buffers P[2][16]
     assert PB + 32 <= min(c.V_WOFF + 32, 256), (PB, c.V_WOFF)               # below the registers that survive the loop (V_LANE ...)
     n_late = 4 * (c.NB - c.early_nb)
+    q = []                                                                   # vector-memory operations issued by the epilogue, in order
+    SWB = PB + 32                                                            # W8A8: weight scales of the current / next column block, 2 x 16 registers
+    assert not c.i8 or SWB + 32 <= c.V_LANE, (SWB, c.V_LANE)
+
+    def wait_for(tags):
+        """vmcnt that retires every operation carrying one of `tags` (None: none of them was issued here)"""
+        idx = [i for i, t in enumerate(q) if t in tags]
+        return None if not idx else min(63, len(q) - 1 - idx[-1])
+
+    def sw_loads(nb):
+        for g4 in range(4):
+            I(f"global_load_dwordx4 {vreg(SWB + 16 * (nb & 1) + 4 * g4, 4)}, {vreg(EA + 5)}, {sreg(S_SW, 2)} offset:{128 * nb + 32 * g4}")
+        q.extend([("sw", nb)] * 4)
+
     for nb in range(c.early_nb, c.NB):                                       # lane needs columns 32 nb + 8 g4 + 4 h + (0..3): 4 loads of 8 bytes
         for g4 in range(4):
             I(f"global_load_dwordx2 {vreg(BB + 8 * nb + 2 * g4, 2)}, {vreg(EA + 2)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
+        q.extend([("bias", nb)] * 4)
+    if c.i8:
+        sw_loads(0)
+        for mb in range(c.MB):                                               # (sx, sx) pairs for the packed multiplies
+            I(f"v_mov_b32 {vreg(c.V_SX + 2 * mb + 1)}, {vreg(c.V_SX + 2 * mb)}")
     blocks = [(nb, mb) for nb in range(c.NB) for mb in range(c.MB)]
     nl = c.nl
 
     for j, (nb, mb) in enumerate(blocks):
         P = c.V_E0 if j == 0 else PB + 16 * (j & 1)
+        if c.i8 and mb == 0 and nb + 1 < c.NB:
+            sw_loads(nb + 1)
         if nl and j + 1 < len(blocks):
             epi_block_loads(g, c, j + 1, PB + 16 * ((j + 1) & 1))
+            q.extend([("blk", j + 1)] * nl)
         nxt_loads = nl if (nl and j + 1 < len(blocks)) else 0
-        if nl and j == 0:
+        if c.i8:                                                             # waits counted from the issue order
+            need = [("blk", j)] + ([("bias", nb), ("sw", nb)] if mb == 0 else [])
+            n = wait_for(need)
+            if n is not None:
+                I(f"s_waitcnt vmcnt({n})")
+        elif nl and j == 0:
             I(f"s_waitcnt vmcnt({(n_late if c.early_nb else 0) + nxt_loads})")   # block 0's pieces are early; its bias vector is late only when none fit up there
         elif nl:                                                             # younger than block j's loads: block j-1's two stores, block j+1's loads
             I(f"s_waitcnt vmcnt({2 + nxt_loads})")
@@ -433,6 +476,12 @@ def gen_epilogue(g: Gen, c: Cfg):
         # v = bf16(acc + bias), kept as f32 in T+0..15
         for r in range(16):
             I(f"v_accvgpr_read_b32 {vreg(T + r)}, {areg(a0 + r)}")
+        if c.i8:                                                             # acc_f * (sx[m] * sw[n]) with gemm_common.h's order of operations
+            for r in range(16):
+                I(f"v_cvt_f32_i32 {vreg(T + r)}, {vreg(T + r)}")
+            for r in range(0, 16, 2):
+                I(f"v_pk_mul_f32 {vreg(T + 56, 2)}, {vreg(SWB + 16 * (nb & 1) + r, 2)}, {vreg(c.V_SX + 2 * mb, 2)}")
+                I(f"v_pk_mul_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 56, 2)}")
         for r in range(0, 16, 2):
             I(f"v_pk_add_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 24 + r, 2)}")
         for r in range(0, 16, 2):                                            # round to bf16 and back
@@ -491,11 +540,13 @@ def gen_epilogue(g: Gen, c: Cfg):
         for k in (0, 2):
             I(f"global_store_dwordx4 {vreg(EA + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
         I("s_mov_b64 exec, -1")
+        q.extend([("st", j)] * 2)
 
 
 if __name__ == "__main__":
     WN, epi = int(sys.argv[1]), int(sys.argv[2])
-    txt = generate(WN, epi, f"GA{WN}E{epi}")
+    i8 = len(sys.argv) > 5 and sys.argv[5] == "i8"
+    txt = generate(WN, epi, f"GA{WN}E{epi}" + ("I8" if i8 else ""), i8)
     probs = lint(txt)
     for p in probs[:20]:
         print("LINT:", p, file=sys.stderr)

@@ -170,13 +170,78 @@ def test_gemm_asm_random_geometries():
             assert (g == w).mean() > 0.93 and np.abs(g - w).max() < 0.13, (tag, (g == w).mean(), np.abs(g - w).max())
 
 
+def run_case_i8(WN, epi, mode, rows_valid=150, K=512, seed=0, m0=256, frame_len=90):
+    """W8A8 form: int8 operands, exact int32 sums, v = bf16(float(acc) * (sx[m] * sw[n]) + bias) (gemm_common.h), same epilogues."""
+    rng = np.random.default_rng(seed)
+    text = G.generate(WN, epi, f"Q{WN}E{epi}", True)
+    assert G.lint(text) == []
+    N = WN
+    x = rng.integers(-127, 128, (rows_valid, K)).astype(np.int8)
+    w = rng.integers(-127, 128, (N, K)).astype(np.int8)
+    sx = (0.5 + rng.random(rows_valid)).astype(np.float32) / np.float32(127 * np.sqrt(K))
+    sw = (0.5 + rng.random(N)).astype(np.float32) / np.float32(40)
+    bias = bf(0.1 * rng.standard_normal(N))
+    res = bf(rng.standard_normal((rows_valid, N)))
+    nframes = (m0 + rows_valid - 1) // frame_len + 1
+    gate = bf(0.5 * rng.standard_normal((nframes, N)))
+    mem = E.Memory()
+    ax, aw, ab, ar, ag, asx, asw = (mem.alloc(t) for t in (x, w, bias, res, gate, sx, sw))
+    ay = mem.alloc(np.full((rows_valid, N), 0x7FC0, dtype=np.uint16))
+    m = E.Machine(text, mem, 4, mode=mode, lds_bytes=G.Cfg(WN, epi, True).lds_bytes)
+    for wv in m.waves:
+        s = wv.s
+        def put64(i, val):
+            s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
+        put64(G.S_X, ax); put64(G.S_W, aw); put64(G.S_Y, ay); put64(G.S_BIAS, ab); put64(G.S_RES, ar); put64(G.S_GATE, ag)
+        put64(G.S_SX, asx); put64(G.S_SW, asw)
+        s[G.S_LDX], s[G.S_LDW], s[G.S_LDO] = K, K, N * 2
+        s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 128
+        s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
+        s[G.S_ROWLO] = 0
+        wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
+        wv.v[1:] = 0x7FC0BEEF
+        wv.a[:] = 0x7FC0BEEF
+    m.run()
+    got = f32(mem.get(ay).view(np.uint16).reshape(rows_valid, N)).astype(np.float64)
+    acc = (x.astype(np.int64) @ w.astype(np.int64).T).astype(np.float32)
+    scl = (sx[:, None] * sw[None, :]).astype(np.float32)
+    v = rbf((acc * scl).astype(np.float32) + f32(bias)[None, :])
+    if epi == G.EPI_BIAS:
+        want = v
+    elif epi == G.EPI_GELU:
+        xx = v.astype(np.float32)
+        k0, k1, ce = np.float32(0.7978845608028654), np.float32(0.044715), np.float32(-2.0 * 1.4426950408889634)
+        u = k0 * (xx + ((k1 * xx) * xx) * xx)
+        e = np.exp2((ce * u).astype(np.float64)).astype(np.float32)
+        want = rbf(xx * (np.float32(1.0) / (np.float32(1.0) + e)))
+    elif epi == G.EPI_RES:
+        want = rbf(f32(res) + v)
+    else:
+        frames = (m0 + np.arange(rows_valid)) // frame_len
+        want = rbf(f32(res) + rbf(v * f32(gate)[frames]))
+    return got, want.astype(np.float64)
+
+
+@pytest.mark.parametrize("WN,epi,mode", [(128, G.EPI_BIAS, "lazy"), (128, G.EPI_GATE_RES, "lazy"), (128, G.EPI_RES, "mixed"),
+                                         (192, G.EPI_BIAS, "eager"), (224, G.EPI_GELU, "lazy")])
+def test_gemm_asm_w8a8(WN, epi, mode):
+    """The W8A8 variant (v_mfma_i32_32x32x32_i8, scales applied in the epilogue): integer sums are exact, so the bias epilogue
+    must reproduce the rounding-point reference bit for bit; the others within the bf16 kernels' bounds."""
+    got, want = run_case_i8(WN, epi, mode)
+    assert np.isfinite(got).all()
+    if epi == G.EPI_BIAS:
+        assert (got == want).all(), np.abs(got - want).max()
+    else:
+        assert (got == want).mean() > 0.97 and np.abs(got - want).max() < 0.07, ((got == want).mean(), np.abs(got - want).max())
+
+
 def test_gemm_asm_text_assembles(tmp_path):
     clang = "/opt/rocm/lib/llvm/bin/clang"
     if not os.path.exists(clang):
         pytest.skip("no ROCm assembler here")
-    for epi in (G.EPI_BIAS, G.EPI_GELU, G.EPI_GATE_RES, G.EPI_RES):
+    for epi, i8 in [(e, False) for e in (G.EPI_BIAS, G.EPI_GELU, G.EPI_GATE_RES, G.EPI_RES, G.EPI_PARTIAL)] + [(G.EPI_GELU, True), (G.EPI_GATE_RES, True)]:
         src = tmp_path / f"k{epi}.s"
-        src.write_text('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n.text\nkernel:\n' + G.generate(224, epi, f"A{epi}"))
+        src.write_text('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n.text\nkernel:\n' + G.generate(224, epi, f"A{epi}", i8))
         r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "k.o")],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[:2000]

@@ -739,6 +739,39 @@ def test_gemm_splitk_l2_exchange_matches(ops, splitk_kernel):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4680, 8960, 1536, "gelu"), (4680, 1536, 8960, "gate"), (4680, 1536, 1536, "gate"),
+                                       (4680, 1536, 1536, "res"), (4680, 1536, 1536, "bias"), (4680, 4608, 1536, "bias"),
+                                       (300, 224, 512, "gelu"), (70, 128, 640, "bias"), (9360, 1536, 1536, "gate")])
+def test_gemm_asm_w8a8_equals_the_hip_w8a8_kernels(ops, M, N, K, epi):
+    """The W8A8 variants of the generated kernels (tuning gemm_asm bit 4; v_mfma_i32_32x32x32_i8, scales in the epilogue): integer
+    sums are exact and the epilogue applies gemm_common.h's operations in its order; only the fp32 exp / rcp of the GELU may round
+    differently from the compiler's code."""
+    x = hn("ix", (M, K), device=DEV)
+    w = (hn("iw", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("ib", (N,), 0.1, device=DEV)
+    xq, sx = ops.quantize_rows(x)
+    wq, sw = ops.quantize_rows(w)
+    kw = {}
+    code = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "gate": ops.EPI_BIAS_GATE_RES, "res": ops.EPI_BIAS_RES}[epi]
+    if epi in ("gate", "res"):
+        kw["res"] = hn("ir", (M, N), device=DEV)
+    if epi == "gate":
+        F_ = 3 if M % 3 == 0 else 1
+        kw.update(e=hn("ie", (1, F_, 6, N), 0.5, device=DEV), mod=None, gate_idx=5, rows_per_batch=M, frame_len=M // F_)
+    want = ops.gemm_w8a8(xq, sx, wq, sw, b, code, **kw)
+    try:
+        _set_tuning("gemm_asm", 19)
+        got = ops.gemm_w8a8(xq, sx, wq, sw, b, code, **kw)
+        again = ops.gemm_w8a8(xq, sx, wq, sw, b, code, **kw)
+    finally:
+        _set_tuning("gemm_asm", 3)
+    assert torch.equal(got, again)
+    if epi == "gelu":
+        assert_bf16_close(got, want, 1, 0.995, f"w8a8 asm {M}x{N}x{K} {epi}")
+    else:
+        assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+
+
 def test_gemm_w8a8_splitk_is_exact(ops):
     """W8A8 split-K: the halves exchange int32 sums, so the result equals the unsplit kernel's bit for bit."""
     M, N, K = 4680, 1536, 8960

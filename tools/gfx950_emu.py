@@ -668,6 +668,29 @@ class Machine:
         for r in range(16):
             self.wv(w, D, res[r], r)
 
+    def i_v_mfma_i32_32x32x32_i8(self, w, i):
+        """A / B: 16 int8 per lane (4 dwords): A[row l & 31][k = 16 (l >> 5) + j], B[k][col l & 31]; int32 accumulate; C/D layout as
+        every 32x32 form.  (The k order inside the instruction is not documented for i8; any order common to A and B gives the
+        same sums, and the GEMM feeds both operands through the same addressing.)"""
+        self.full_exec(w, "mfma")
+        D, A, B, C = i.ops
+        lanes = np.arange(64)
+        Am = np.zeros((32, 32), dtype=np.int64); Bm = np.zeros((32, 32), dtype=np.int64)
+        for d in range(4):
+            xa, xb = self.rv(w, A, d), self.rv(w, B, d)
+            for b in range(4):
+                k = 16 * (lanes >> 5) + 4 * d + b
+                Am[lanes & 31, k] = ((xa >> (8 * b)) & U32(0xFF)).astype(np.uint8).view(np.int8)
+                Bm[k, lanes & 31] = ((xb >> (8 * b)) & U32(0xFF)).astype(np.uint8).view(np.int8)
+        P = Am @ Bm
+        res = []
+        for r in range(16):
+            rows = (r & 3) + 8 * (r >> 2) + 4 * (lanes >> 5)
+            c = np.zeros(64, dtype=np.int64) if C.kind == "imm" else self.rv(w, C, r).view(np.int32).astype(np.int64)
+            res.append(((c + P[rows, lanes & 31]) & 0xFFFFFFFF).astype(np.uint32))
+        for r in range(16):
+            self.wv(w, D, res[r], r)
+
     def i_v_mfma_f32_16x16x32_bf16(self, w, i):
         self.full_exec(w, "mfma")
         D, A, B, C = i.ops
