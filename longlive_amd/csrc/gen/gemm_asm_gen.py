@@ -288,8 +288,10 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
     if KN("NO_EPI"):
         I("s_waitcnt vmcnt(0)")
         I("s_endpgm")
-    gen_epilogue(g, c)
-    I("s_waitcnt vmcnt(0)")
+    tail_stores = gen_epilogue(g, c)
+    # every load of the wave (the over-run staging pieces included: they are older) has landed once at most the epilogue's trailing
+    # stores are outstanding; the wave does not wait for those to be acknowledged
+    I(f"s_waitcnt vmcnt({min(63, tail_stores)})")
     I("s_endpgm")
     # ================= idle waves: their share of W, the barriers =================
     g.L(f"{prefix}_IDLE")
@@ -414,7 +416,7 @@ def gen_epilogue(g: Gen, c: Cfg):
                 for g4 in range(4):
                     I(f"global_store_dwordx4 {vreg(EA + mb)}, {vreg(T + 4 * g4, 4)}, {sreg(S_Y, 2)} offset:{128 * nb + 32 * g4}")
                 I("s_mov_b64 exec, -1")
-        return
+        return 4 * c.NB * c.MB
     # Every global read of the epilogue is issued ahead of its use: the early ones before the loop (gen_epilogue_setup), here the
     # bias vectors that did not fit up there, then the gate / residual pieces of block j + 1 while block j computes.
     BB, PB = T + 72, T + 72 + 8 * c.NB                                       # late bias raw [nb][g4] (2 registers each); block buffers P[2][16]
@@ -541,6 +543,10 @@ def gen_epilogue(g: Gen, c: Cfg):
             I(f"global_store_dwordx4 {vreg(EA + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
         I("s_mov_b64 exec, -1")
         q.extend([("st", j)] * 2)
+    n = 0
+    while n < len(q) and q[len(q) - 1 - n][0] == "st":
+        n += 1
+    return n
 
 
 if __name__ == "__main__":
