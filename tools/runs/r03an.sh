@@ -1,6 +1,6 @@
 # last check of the round: smoke + the whole GPU suite + the driver's bench invocation on the final commit
 set -u
-O=gpurun_out/r03an; mkdir -p $O
+O=gpurun_out/r03aw; mkdir -p $O
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $O/gputests.log
 [ $rc -eq 0 ] || { grep -E "^E |^FAILED" $O/gputests.log | head -20; exit $rc; }
