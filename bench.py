@@ -336,7 +336,7 @@ def _plan_text(fn, *a):
     return buf.value.decode()
 
 
-def kernel_table(summary, quant, splitk=False):
+def kernel_table(summary, quant, splitk=False, mod_table=True):
     """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac)."""
     from longlive_amd import _lib
     lib = _lib.load()
@@ -355,7 +355,10 @@ def kernel_table(summary, quant, splitk=False):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
             epi = {"gemm_qkv": 0, "gemm_o": 2, "gemm_cq": 0, "gemm_co": 3, "gemm_f1": 1, "gemm_f2": 2}[tag]      # LL_EPI_* of the call
-            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, 2 if tag == "gemm_qkv" else 1,
+            # plain: 2 = the fused QKV call (V redirect), 1 = an ordinary call, 0 = a per-batch modulation vector rides along
+            # (gate-residual calls when the model runs with use_modulation_table = False: those take the HIP kernels)
+            plain = 2 if tag == "gemm_qkv" else (0 if (epi == 2 and not mod_table) else 1)
+            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, plain,
                               1 if (tag == "gemm_f2" and splitk and not i8) else 0)                              # int8: _lin drops split-K
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)
@@ -628,7 +631,8 @@ def run_replica(args, rank, world, local_rank, sync):
             blk_ms = 1e3 * (time.perf_counter() - t0)
             summ = ops.timer.summary()
             ops.timer = None
-            rows = kernel_table(summ, quant, splitk=bool(getattr(gen.model, "ffn2_splitk", False)))
+            rows = kernel_table(summ, quant, splitk=bool(getattr(gen.model, "ffn2_splitk", False)),
+                                mod_table=bool(getattr(gen.model, "use_modulation_table", True)))
             res["kernels"] = {"note": "one untimed steady-state block, HIP events around every launch (adds ~2 us of gap per launch: "
                                       f"this block took {blk_ms:.1f} ms); shares are of the sum of kernel time",
                               "sum_kernel_ms": sum(r["total_ms"] for r in rows), "rows": rows}

@@ -157,7 +157,9 @@ int ll_gemm_w8a8_splitk(const int8_t* xq, const float* sx, const int8_t* wq, con
  * taken for this shape on this device), each range's fp32 tile sums go to `workspace` ([splits][M][N] floats, caller-owned, at
  * least ll_gemm_ksplit_workspace_bytes bytes, 16-byte aligned, no initialisation needed) and one pass adds them in a fixed order
  * and applies the epilogue (LL_EPI_BIAS or LL_EPI_BIAS_RES).  Results equal ll_gemm_bf16's up to the order of the fp32 sum;
- * bit-identical run to run.  workspace = NULL or plan = 0: it IS ll_gemm_bf16. */
+ * bit-identical run to run.  workspace = NULL or plan = 0: it IS ll_gemm_bf16.  The NUMBER of ranges depends on N and K only;
+ * WHETHER the path is taken depends on M and on the device's CU count (tiles * 2 <= CUs) and on tuning key "gemm_asm"
+ * (bit 0 off or bit 3 set: never), so a row's fp32 sum order is stable only inside that region. */
 int ll_gemm_ksplit_plan(int M, int N, int K);
 long long ll_gemm_ksplit_workspace_bytes(int M, int N, int K);
 int ll_gemm_bf16_ksplit(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
@@ -234,6 +236,12 @@ int ll_add_noise(const ll_bf16* x0, const ll_bf16* noise, const float* sigma, ll
  * (utils/wan_wrapper.py:195-197; utils/scheduler.py:172-174).  All fp32 device arrays; lowest index wins ties. */
 int ll_sigma_lookup(const float* t, const float* timesteps, const float* sigmas, float* out, int n, int n_table,
                     ll_stream stream);
+
+/* Synthetic data for bench.py / the tests (no reference call site: the reference loads checkpoints, inference.py:72-94, and draws
+ * noise with torch.randn, :193-195): out[i] (fp32, device) = the counter hash of longlive_amd/synth.py at counter lo + i under
+ * stream_const -- kind 0: uniform [0, 1) with 24 bits, kind 1: Irwin-Hall normal.  Bit-identical to synth.hash_uniform /
+ * hash_normal on any host (csrc/synth_hash.h is compiled for both sides; tests/test_synth_hash.py). */
+int ll_synth_hash(float* out, long long lo, long long n, unsigned long long stream_const, int kind, ll_stream stream);
 
 /* ---- VAE decoder (wan/modules/vae.py, utils/wan_wrapper.py:83-116) ------------------- */
 

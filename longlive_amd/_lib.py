@@ -51,6 +51,7 @@ SIGNATURES = {
     "ll_unpatchify_x0": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ll_add_noise": [_p, _p, _p, _p, _i, _ll, _p],
     "ll_sigma_lookup": [_p, _p, _p, _p, _i, _i, _p],
+    "ll_synth_hash": [_p, _ll, _ll, C.c_ulonglong, _i, _p],
     "ll_conv_cl": [_p] * 6 + [_i] * 10 + [_p],
     "ll_rms_silu_cl": [_p, _p, _p, _ll, _i, _i, _p],
     "ll_softmax_rows": [_p, _p, _i, _i, _i, _f, _p],

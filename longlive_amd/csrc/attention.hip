@@ -1244,15 +1244,10 @@ static int flash_attn_pipe_launch(const ll_bf16* q, const ll_bf16* k, const ll_b
                                          int Lq, int H, int ldq, int ldo, int ldk, long long k_batch_stride, int kstart,
                                          int nkeys, float c, ll_stream stream) {
   constexpr int NW = 8;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B));
-    (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
-    (void)hipFuncSetAttribute((const void*)flash_attn_pipe16_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
-    attr = true;
+  {
+    (void)ll_lds_attr((const void*)flash_attn_pipe_kernel<NW, 0>, (int)((PIPE_KSTAGES + PIPE_VSTAGES) * TILE_B));
+    (void)ll_lds_attr((const void*)flash_attn_pipe_kernel<NW, 1>, (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
+    (void)ll_lds_attr((const void*)flash_attn_pipe16_kernel<NW>, (int)((PIPE_KSTAGES + PIPE_VSTAGES + 2) * TILE_B));
   }
   int nqt = (Lq + NW * 32 - 1) / (NW * 32);
   dim3 grid(nqt * H, 1, B), block(NW * 64);
@@ -1321,7 +1316,7 @@ extern "C" int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_l
                "flash_attn_sk_combine_kernel<8>", W, ((long long)nqt * H * B * ((n0 + KT - 1) / KT) + W - 1) / W);
     else if (attn_asm_eligible(n0, H * 128))
       snprintf(out, (size_t)cap, "%s (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups of 256 query rows%s",
-               "flash_attn_asm_kernel", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
+               "flash_attn_asm_kernel", nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : ""), ll_plan_append_knobs(out, cap);
     else if (pp && g_attn_mfma16)
       snprintf(out, (size_t)cap, "flash_attn_pipe16_kernel<8> (ping-pong wave groups, MFMA 16x16x32), %d workgroups of 256 query rows%s",
                nqt * H * B, g_attn_xcd ? ", XCD-aware placement" : "");
@@ -1338,11 +1333,8 @@ static int flash_attn_sk_launch(const ll_bf16* q, const ll_bf16* k, const ll_bf1
                                 int ldq, int ldo, int ldk, long long k_batch_stride, int kstart, int nkeys, float c,
                                 float* ws, int W, ll_stream stream) {
   constexpr int NW = 8;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)flash_attn_sk_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((SK_KSTAGES + SK_VSTAGES) * TILE_B));
-    attr = true;
+  {
+    (void)ll_lds_attr((const void*)flash_attn_sk_kernel<NW>, (int)((SK_KSTAGES + SK_VSTAGES) * TILE_B));
   }
   const int nqt = (Lq + NW * 32 - 1) / (NW * 32), npairs = B * H * nqt;
   hipLaunchKernelGGL((flash_attn_sk_kernel<NW>), dim3(W), dim3(NW * 64), (SK_KSTAGES + SK_VSTAGES) * TILE_B, (hipStream_t)stream,

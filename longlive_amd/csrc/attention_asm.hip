@@ -14,11 +14,7 @@
 #undef LL_ASM_INC
 int flash_attn_asm_launch(const bf16* q, const bf16* k, const bf16* v, bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk,
                           long long k_batch_stride, int kstart, int nkeys, float c, int xcd, int form, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)flash_attn_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr = true;
-  }
+  if (int rc = ll_lds_attr((const void*)flash_attn_asm_kernel, 128 * 1024)) return rc;
   const int nqt = (Lq + 255) / 256;
   (void)form;
   hipLaunchKernelGGL(flash_attn_asm_kernel, dim3(nqt * H, 1, B), dim3(256), 128 * 1024, stream, q, k, v, out, Lq, ldq, ldo, ldk,

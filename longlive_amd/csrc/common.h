@@ -60,3 +60,5 @@ void ll_set_error(const char* fmt, ...);
   } while (0)
 
 int ll_check_launch(const char* what);
+int ll_lds_attr(const void* fn, int bytes);      // dynamic-LDS limit of a kernel, set once per (kernel, device); LL_OK or an error code
+void ll_plan_append_knobs(char* out, int cap);   // " [generator knobs: ...]" when the library was built with non-default ASM_* knobs

@@ -528,11 +528,9 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
       dim3 hgrid((unsigned)nwg), hblock(512);
 #define HL_LAUNCH(E, NCBV, UPV)                                                                                        \
       do {                                                                                                             \
-        static bool attr = false;                                                                                      \
-        if (!attr) {                                                                                                   \
-          (void)hipFuncSetAttribute((const void*)conv_halo_kernel<E, NCBV, UPV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        {                                                                                      \
+          (void)ll_lds_attr((const void*)conv_halo_kernel<E, NCBV, UPV>, \
                                     (int)HL_LDS(NCBV, UPV));                                                           \
-          attr = true;                                                                                                 \
         }                                                                                                              \
         hipLaunchKernelGGL((conv_halo_kernel<E, NCBV, UPV>), hgrid, hblock, HL_LDS(NCBV, UPV), s, (const char*)x,      \
                            (const char*)zero16, (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo,  \
@@ -558,10 +556,8 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
   size_t lds = 3 * CV_STAGE;
 #define CV_LAUNCH(E, NTV, MD)                                                                                          \
   do {                                                                                                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)conv_cl_kernel<E, NTV, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr = true;                                                                                                     \
+    {                                                                                          \
+      (void)ll_lds_attr((const void*)conv_cl_kernel<E, NTV, MD>, (int)lds); \
     }                                                                                                                  \
     hipLaunchKernelGGL((conv_cl_kernel<E, NTV, MD>), grid, block, lds, s, g, (const char*)w, (bf16*)out, M, Cout, nk,   \
                        (size_t)Kpad * 2, ldo, ntm, ntn, ea);                                                           \

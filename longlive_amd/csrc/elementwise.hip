@@ -594,3 +594,27 @@ extern "C" int ll_sigma_lookup(const float* t, const float* timesteps, const flo
   hipLaunchKernelGGL(sigma_lookup_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, t, timesteps, sigmas, out, n_table);
   return ll_check_launch("ll_sigma_lookup");
 }
+
+// ---- synthetic data (bench.py / tests: there are no checkpoints or datasets here) -----------------------------------------------
+// out[i] = hash_normal / hash_uniform of counter lo + i under `stream_const` -- the same integers longlive_amd/synth.py evaluates
+// with int64 tensor ops, so the bits are identical on any host and on the device.  In the library because torch's int64
+// elementwise kernels are what a python process under `rocprofv3 --pmc` dies in on this image (profiles/r03_pmc_inpipe.md,
+// DESIGN.md): with this kernel bench.py issues none of them.
+#include "synth_hash.h"
+__global__ __launch_bounds__(256) void synth_hash_kernel(float* __restrict__ out, unsigned long long lo, long long n,
+                                                         unsigned long long stream_const, int kind) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t idx = (uint64_t)lo + (uint64_t)i;
+  out[i] = kind == 0 ? ll_synth_uniform(idx, (uint64_t)stream_const) : ll_synth_normal(idx, (uint64_t)stream_const);
+}
+
+extern "C" int ll_synth_hash(float* out, long long lo, long long n, unsigned long long stream_const, int kind, ll_stream stream) {
+  LL_REQUIRE(kind == 0 || kind == 1, "ll_synth_hash: kind %d (0 = uniform, 1 = normal)", kind);
+  LL_REQUIRE(n >= 0 && lo >= 0 && (n + 255) / 256 < (1ll << 31), "ll_synth_hash: bad range lo=%lld n=%lld", lo, n);
+  if (n == 0) return LL_OK;
+  LL_REQUIRE(out != nullptr, "ll_synth_hash: out is NULL");
+  hipLaunchKernelGGL(synth_hash_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     (unsigned long long)lo, n, stream_const, kind);
+  return ll_check_launch("ll_synth_hash");
+}

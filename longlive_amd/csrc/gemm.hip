@@ -874,7 +874,8 @@ int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16*
                            int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s, const bf16* norm_w,
                            float eps, bf16* h_out);
 extern "C" int ll_t5_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int rows, int C, float eps, ll_stream stream);
-const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap);
+const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap, bool i8);
+int gemm_asm_width_i8(int M, int N, int K, int epilogue, bool plain, bool has_v, bool v_ok, int frame_len);
 static bool gemm_asm_wanted(int epilogue) {
   return (g_gemm_asm & 1) && !((g_gemm_asm & 4) && epilogue == LL_EPI_BIAS_GELU) && !((g_gemm_asm & 8) && epilogue != LL_EPI_BIAS_GELU);
 }
@@ -884,12 +885,14 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
                        int ldo, int epilogue, const EpiArgs& ea, hipStream_t s) {
   // gemm_asm: bit 0 = generated kernels for the shapes they cover, bit 1 = also instead of split-K; bit 2 / bit 3 leave the
   // GELU (256 x 224) / the 128-wide kernels out (A/B of their share in the pipeline's power budget)
-  if (!I8 && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2 &&
-      gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s))
-    return 0;
-  if (I8 && (g_gemm_asm & 16) && gemm_asm_wanted(epilogue) && xrow_bytes == (size_t)K && wrow_bytes == (size_t)K &&      // bit 4: W8A8 on the generated kernels
-      gemm_asm_launch_i8((const int8_t*)x, (const int8_t*)w, out, M, N, K, ldo, epilogue, ea, g_gemm_group_m, s))
-    return 0;
+  if (!I8 && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2) {
+    const int r = gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s);
+    if (r) return r < 0 ? r : 0;                      // launched, or failed (error code); 0 = not covered: the HIP kernels below
+  }
+  if (I8 && (g_gemm_asm & 16) && gemm_asm_wanted(epilogue) && xrow_bytes == (size_t)K && wrow_bytes == (size_t)K) {      // bit 4: W8A8 on the generated kernels
+    const int r = gemm_asm_launch_i8((const int8_t*)x, (const int8_t*)w, out, M, N, K, ldo, epilogue, ea, g_gemm_group_m, s);
+    if (r) return r < 0 ? r : 0;
+  }
   const int kbytes = I8 ? K : 2 * K;
   const int nk = kbytes / ROWB;
   const int variant = pick_gemm_variant(M, N);
@@ -905,11 +908,9 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
   size_t lds = v3 ? 2 * V3_STAGE : (v5 || v6) ? 2 * (size_t)(256 + bn) * ROWB : 3 * V2_STAGE;
 #define LAUNCH_WS(E, WM_, WN_, MT_, NT_, ST_, NL_)                                                                     \
   do {                                                                                                                 \
-    static bool aws = false;                                                                                           \
-    if (!aws) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel_ws<E, I8, WM_, WN_, MT_, NT_, ST_, NL_>,                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                 \
-      aws = true;                                                                                                      \
+    {                                                                                           \
+      (void)ll_lds_attr((const void*)gemm_kernel_ws<E, I8, WM_, WN_, MT_, NT_, ST_, NL_>, \
+                                (int)lds);                                 \
     }                                                                                                                  \
     hipLaunchKernelGGL((gemm_kernel_ws<E, I8, WM_, WN_, MT_, NT_, ST_, NL_>), grid, dim3(512 + 64 * NL_), lds, s,      \
                        (const char*)x, (const char*)w, out, M, N, nk, xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea); \
@@ -925,11 +926,9 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
     if (wsn == 1 && variant == 2) { LAUNCH_WS(E, 4, 2, 4, 4, 3, 1); break; }                                           \
     if (wsn == 2 && variant == 2) { LAUNCH_WS(E, 4, 2, 4, 4, 3, 2); break; }                                           \
     if (v5 || v6) {                                                                                                    \
-      static bool a5 = false;                                                                                          \
-      if (!a5) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<E, I8, 2, 4, 8, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * ROWB); \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<E, I8, 4, 2, 4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 224) * ROWB); \
-        a5 = true;                                                                                                     \
+      {                                                                                          \
+        (void)ll_lds_attr((const void*)gemm_kernel_v5<E, I8, 2, 4, 8, 3>, 2 * (256 + 192) * ROWB); \
+        (void)ll_lds_attr((const void*)gemm_kernel_v5<E, I8, 4, 2, 4, 7>, 2 * (256 + 224) * ROWB); \
       }                                                                                                                \
       if (v5)                                                                                                          \
         hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 2, 4, 8, 3>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
@@ -938,27 +937,21 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
         hipLaunchKernelGGL((gemm_kernel_v5<E, I8, 4, 2, 4, 7>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
                            xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                 \
     } else if (v4) {                                                                                                   \
-      static bool a4 = false;                                                                                          \
-      if (!a4) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v4<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        a4 = true;                                                                                                     \
+      {                                                                                          \
+        (void)ll_lds_attr((const void*)gemm_kernel_v4<E, I8>, (int)lds); \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v4<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
                          xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                   \
     } else if (v3) {                                                                                                   \
-      static bool a3 = false;                                                                                          \
-      if (!a3) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<E, I8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        a3 = true;                                                                                                     \
+      {                                                                                          \
+        (void)ll_lds_attr((const void*)gemm_kernel_v3<E, I8>, (int)lds); \
       }                                                                                                                \
       hipLaunchKernelGGL((gemm_kernel_v3<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
                          xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                                   \
     } else {                                                                                                           \
-      static bool a2 = false;                                                                                          \
-      if (!a2) {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<E, I8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        (void)hipFuncSetAttribute((const void*)gemm_kernel_v2<E, I8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        a2 = true;                                                                                                     \
+      {                                                                                          \
+        (void)ll_lds_attr((const void*)gemm_kernel_v2<E, I8, false>, (int)lds); \
+        (void)ll_lds_attr((const void*)gemm_kernel_v2<E, I8, true>, (int)lds); \
       }                                                                                                                \
       if (g_gemm_stagger)                                                                                              \
         hipLaunchKernelGGL((gemm_kernel_v2<E, I8, true>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
@@ -1004,7 +997,7 @@ extern "C" int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b
   if (M == 0) return LL_OK;
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, (const bf16*)e, (const bf16*)mod, nullptr, nullptr, nmod, gate_idx,
              rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
-  launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream);
+  if (int lrc = launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream)) return lrc;
   return ll_check_launch("ll_gemm_bf16");
 }
 
@@ -1012,7 +1005,7 @@ extern "C" int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b
 // shape already fills half the device, N % 128, K too short, no device, or the generated kernels are switched off).
 static int device_cus();
 extern "C" int ll_gemm_ksplit_plan(int M, int N, int K) {
-  if (!(g_gemm_asm & 1)) return 0;
+  if (!gemm_asm_wanted(LL_EPI_BIAS)) return 0;        // bit 0 off, or bit 3 ("leave the 128-wide kernels out"): gemm_asm_128_partial is one of them
   return gemm_ksplit_splits(M, N, K, device_cus());
 }
 extern "C" long long ll_gemm_ksplit_workspace_bytes(int M, int N, int K) {
@@ -1033,12 +1026,12 @@ extern "C" int ll_gemm_bf16_ksplit(const ll_bf16* x, const ll_bf16* w, const ll_
   if (S >= 2 && workspace != nullptr && ldo % 8 == 0) {
     LL_REQUIRE(workspace_bytes >= (long long)S * M * N * 4 && ((size_t)workspace & 15) == 0,
                "ll_gemm_bf16_ksplit: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes, (long long)S * M * N * 4);
-    if (gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, epilogue,
-                               (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream, nullptr, 0.f, nullptr))
-      return ll_check_launch("ll_gemm_bf16_ksplit");
+    const int r = gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, epilogue,
+                                         (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream, nullptr, 0.f, nullptr);
+    if (r) return r < 0 ? r : ll_check_launch("ll_gemm_bf16_ksplit");
   }
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
-  launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream);
+  if (int lrc = launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, epilogue, ea, (hipStream_t)stream)) return lrc;
   return ll_check_launch("ll_gemm_bf16_ksplit");
 }
 
@@ -1060,10 +1053,10 @@ extern "C" int ll_gemm_bf16_ksplit_t5norm(const ll_bf16* x, const ll_bf16* w, co
   if (S >= 2 && workspace != nullptr && N <= 4096) {
     LL_REQUIRE(workspace_bytes >= (long long)S * M * N * 4 && ((size_t)workspace & 15) == 0,
                "ll_gemm_bf16_ksplit_t5norm: workspace of %lld bytes, need %lld (16-byte aligned)", workspace_bytes, (long long)S * M * N * 4);
-    if (gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, LL_EPI_BIAS_RES,
-                               (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream, (const bf16*)norm_w, eps,
-                               (bf16*)h_out))
-      return ll_check_launch("ll_gemm_bf16_ksplit_t5norm");
+    const int r = gemm_asm_ksplit_launch((const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)out, M, N, K, ldx, ldo, LL_EPI_BIAS_RES,
+                                         (const bf16*)res, (float*)workspace, S, g_gemm_group_m, (hipStream_t)stream, (const bf16*)norm_w, eps,
+                                         (bf16*)h_out);
+    if (r) return r < 0 ? r : ll_check_launch("ll_gemm_bf16_ksplit_t5norm");
   }
   rc = ll_gemm_bf16_ksplit(x, w, bias, out, M, N, K, ldx, ldo, LL_EPI_BIAS_RES, res, workspace, workspace_bytes, stream);
   if (rc) return rc;
@@ -1144,7 +1137,11 @@ extern "C" int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int
   if (!int8 && gemm_asm_wanted(epilogue) && (!sk || (g_gemm_asm & 2))) {
     // plain: 1 = an ordinary call, 0 = per-batch modulation vector (HIP kernels), 2 = the fused QKV call with its V redirect (B = 1)
     const int wn = gemm_asm_width(M, N, K, K, epilogue, plain != 0, plain == 2, plain == 2 && (2 * (N / 3)) % 192 == 0, 1);
-    if (wn) { gemm_asm_plan(M, N, wn, epilogue, out, cap); return LL_OK; }
+    if (wn) { gemm_asm_plan(M, N, wn, epilogue, out, cap, false); ll_plan_append_knobs(out, cap); return LL_OK; }
+  }
+  if (int8 && (g_gemm_asm & 16) && gemm_asm_wanted(epilogue) && !sk) {      // bit 4: W8A8 calls on the generated kernels (launch_gemm<true>)
+    const int wn = gemm_asm_width_i8(M, N, K, epilogue, plain != 0, plain == 2, plain == 2 && (2 * (N / 3)) % 192 == 0, 1);
+    if (wn) { gemm_asm_plan(M, N, wn, epilogue, out, cap, true); ll_plan_append_knobs(out, cap); return LL_OK; }
   }
   if (sk) {
     snprintf(out, (size_t)cap, "gemm_kernel_v4sk<%s> tile 256x256 x split-K 2, %d workgroups, halves reduced in the epilogue",
@@ -1178,14 +1175,15 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
                          hipStream_t s) {
   const int kbytes = I8 ? K : 2 * K;
   if (!splitk_eligible(M, N, kbytes) || workspace == nullptr) {
-    launch_gemm<I8>(x, w, out, M, N, K, xrow_bytes, wrow_bytes, ldo, epilogue, ea, s);
+    if (int lrc = launch_gemm<I8>(x, w, out, M, N, K, xrow_bytes, wrow_bytes, ldo, epilogue, ea, s)) return lrc;
     return ll_check_launch(fn);
   }
   // gemm_asm bit 1: the generated 256 x 128 kernel where it covers the call (measured: 109 us / 145 mJ against 123 us / 166 mJ
   // for the split-K kernel at FFN2's shape, profiles/r03_kenergy_gemm.txt) -- no partner hand-off on that path
-  if (!I8 && (g_gemm_asm & 2) && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2 &&
-      gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s))
-    return ll_check_launch(fn);
+  if (!I8 && (g_gemm_asm & 2) && gemm_asm_wanted(epilogue) && wrow_bytes == (size_t)K * 2) {
+    const int r = gemm_asm_launch((const bf16*)x, (const bf16*)w, out, M, N, K, (int)(xrow_bytes / 2), ldo, epilogue, ea, g_gemm_group_m, s);
+    if (r) return r < 0 ? r : ll_check_launch(fn);
+  }
   LL_REQUIRE(workspace_bytes >= ll_gemm_splitk_workspace_bytes(M, N) && ((size_t)workspace & 15) == 0,
              "%s: workspace of %lld bytes, need %lld (16-byte aligned)", fn, workspace_bytes, ll_gemm_splitk_workspace_bytes(M, N));
   const int tiles = splitk_tiles(M, N), ntn = N / 256, nkh = kbytes / (2 * ROWB);
@@ -1199,11 +1197,9 @@ static int launch_splitk(const char* fn, const void* x, const void* w, bf16* out
   if (epoch == 0) epoch = launch_counter.fetch_add(1u, std::memory_order_relaxed) + 1u;      // 0 = "no flag"
 #define SK_LAUNCH(E)                                                                                                   \
   do {                                                                                                                 \
-    static bool ask = false;                                                                                           \
-    if (!ask) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E, I8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel_v4sk<E, I8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      ask = true;                                                                                                      \
+    {                                                                                           \
+      (void)ll_lds_attr((const void*)gemm_kernel_v4sk<E, I8, false>, (int)lds); \
+      (void)ll_lds_attr((const void*)gemm_kernel_v4sk<E, I8, true>, (int)lds); \
     }                                                                                                                  \
     if (l2)                                                                                                            \
       hipLaunchKernelGGL((gemm_kernel_v4sk<E, I8, true>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nkh, \
@@ -1263,7 +1259,7 @@ extern "C" int ll_gemm_w8a8(const int8_t* xq, const float* sx, const int8_t* wq,
   if (M == 0) return LL_OK;
   EpiArgs ea{(const bf16*)bias, (const bf16*)res, (const bf16*)e, (const bf16*)mod, sx, sw, nmod, gate_idx,
              rows_per_batch, frame_len, frame_len > 0 && rows_per_batch > 0 ? rows_per_batch / frame_len : 0};
-  launch_gemm<true>(xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, epilogue, ea, (hipStream_t)stream);
+  if (int lrc = launch_gemm<true>(xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, epilogue, ea, (hipStream_t)stream)) return lrc;
   return ll_check_launch("ll_gemm_w8a8");
 }
 
@@ -1294,7 +1290,7 @@ extern "C" int ll_gemm_bf16_qkv(const ll_bf16* x, const ll_bf16* w, const ll_bf1
   EpiArgs ea{(const bf16*)bias, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
   ea.v_out = (bf16*)cache_v; ea.v_col0 = 2 * (N / 3); ea.v_C = N / 3; ea.v_L = L; ea.v_S = S;
   ea.v_write_start = write_start; ea.v_roped_offset = roped_offset; ea.v_write_len = write_len;
-  launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, LL_EPI_BIAS, ea, (hipStream_t)stream);
+  if (int lrc = launch_gemm<false>(x, w, (bf16*)out, M, N, K, (size_t)ldx * 2, (size_t)K * 2, ldo, LL_EPI_BIAS, ea, (hipStream_t)stream)) return lrc;
   return ll_check_launch("ll_gemm_bf16_qkv");
 }
 
@@ -1311,7 +1307,7 @@ extern "C" int ll_gemm_w8a8_qkv(const int8_t* xq, const float* sx, const int8_t*
   EpiArgs ea{(const bf16*)bias, nullptr, nullptr, nullptr, sx, sw, 0, 0, 0, 0, 0};
   ea.v_out = (bf16*)cache_v; ea.v_col0 = 2 * (N / 3); ea.v_C = N / 3; ea.v_L = L; ea.v_S = S;
   ea.v_write_start = write_start; ea.v_roped_offset = roped_offset; ea.v_write_len = write_len;
-  launch_gemm<true>(xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, LL_EPI_BIAS, ea, (hipStream_t)stream);
+  if (int lrc = launch_gemm<true>(xq, wq, (bf16*)out, M, N, K, (size_t)K, (size_t)K, ldo, LL_EPI_BIAS, ea, (hipStream_t)stream)) return lrc;
   return ll_check_launch("ll_gemm_w8a8_qkv");
 }
 

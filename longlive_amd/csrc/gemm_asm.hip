@@ -120,7 +120,7 @@ int gemm_asm_width(int M, int N, int K, int ldx, int epilogue, bool plain, bool 
   return 0;
 }
 
-// 1 = launched; 0 = shape / epilogue not covered here (the caller takes the HIP kernels)
+// 1 = launched; 0 = shape / epilogue not covered here (the caller takes the HIP kernels); < 0 = an LL_ERR_* code (attribute / launch failed)
 int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K, int ldx, int ldo, int epilogue, const EpiArgs& ea,
                     int gm, hipStream_t s) {
   const bool has_v = ea.v_out != nullptr;
@@ -132,10 +132,8 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
                    : wn == 192 ? (const void*)gemm_asm_192_bias
                    : epilogue == LL_EPI_BIAS ? (const void*)gemm_asm_128_bias
                    : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asm_128_gate_res : (const void*)gemm_asm_128_res;
-  static bool attr[6] = {false, false, false, false, false, false};
-  const int slot = wn == 224 ? 0 : wn == 256 ? 5 : wn == 192 ? 4 : fn == (const void*)gemm_asm_128_bias ? 1 : fn == (const void*)gemm_asm_128_gate_res ? 2 : 3;
   const int lds = 3 * wn * 128 + 4 * 2 * 8192;      // gen/gemm_asm_gen.py Cfg.lds_bytes: 3 W slots of WN rows x 128 B + 2 X units of 8 KiB per wave
-  if (!attr[slot]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr[slot] = true; }
+  if (int rc = ll_lds_attr(fn, lds)) return rc;
   const int ntm = (M + 255) / 256, ntn = N / wn;
   const bf16* gate = epilogue == LL_EPI_BIAS_GATE_RES ? ea.e + (size_t)ea.gate_idx * N : nullptr;
   const int gstride = ea.nmod * N * 2;
@@ -145,15 +143,26 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
   void* args[] = {(void*)&x, (void*)&w, (void*)&ea.bias, (void*)&out, (void*)&ea.res, (void*)&gate, (void*)&M, (void*)&N, (void*)&K,
                   (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm,
                   (void*)&v_out, (void*)&v_col0, (void*)&v_C, (void*)&v_shift, (void*)&v_lo, (void*)&v_hi};
-  (void)hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s);
+  if (hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s) != hipSuccess) return ll_check_launch("gemm_asm");
   return 1;
 }
 
-const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap) {
+const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap, bool i8) {
   const char* tail = wn == 224 ? "gelu" : wn == 256 ? "bias" : epilogue == LL_EPI_BIAS ? "bias" : epilogue == LL_EPI_BIAS_GATE_RES ? "gate_res" : "res";      // wn == 192: bias
-  snprintf(out, (size_t)cap, "gemm_asm_%d_%s<bf16> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", wn,
-           tail, wn, ((M + 255) / 256) * (N / wn));
+  snprintf(out, (size_t)cap, "gemm_asm%s_%d_%s<%s> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", i8 ? "q" : "", wn,
+           tail, i8 ? "i8" : "bf16", wn, ((M + 255) / 256) * (N / wn));
   return out;
+}
+
+// tile width gemm_asm_launch_i8 takes for a W8A8 call (0 = not covered): the same rule as in that launcher
+int gemm_asm_width_i8(int M, int N, int K, int epilogue, bool plain, bool has_v, bool v_ok, int frame_len) {
+  if (!plain || M <= 0 || K % 128 != 0 || K < 512 || (long long)256 * K >= 0x7fffffffLL) return 0;
+  if (epilogue == LL_EPI_BIAS_GATE_RES && frame_len <= 0) return 0;
+  if (has_v) return (v_ok && epilogue == LL_EPI_BIAS && N % 192 == 0) ? 192 : 0;
+  if (epilogue == LL_EPI_BIAS_GELU) return N % 224 == 0 ? 224 : 0;
+  if (epilogue == LL_EPI_BIAS && N > 2048 && N % 192 == 0) return 192;
+  if (N % 128 == 0 && N <= 2048) return 128;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -254,15 +263,14 @@ int gemm_ksplit_splits(int M, int N, int K, int cus) {
   return S;
 }
 
-// 1 = launched (two launches), 0 = not covered
+// 1 = launched (two launches), 0 = not covered, < 0 = an LL_ERR_* code
 int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, int M, int N, int K, int ldx, int ldo,
                            int epilogue, const bf16* res, float* workspace, int splits, int gm, hipStream_t s, const bf16* norm_w,
                            float eps, bf16* h_out) {
   if (splits < 2 || (epilogue != LL_EPI_BIAS && epilogue != LL_EPI_BIAS_RES) || (ldx % 8) != 0 || (ldo % 8) != 0) return 0;
   if ((long long)256 * ldx * 2 >= 0x7fffffffLL || (long long)256 * K * 2 >= 0x7fffffffLL) return 0;
-  static bool attr = false;
   const int lds = 3 * 128 * 128 + 4 * 2 * 8192;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_asm_128_partial, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
+  if (int rc = ll_lds_attr((const void*)gemm_asm_128_partial, lds)) return rc;
   const int ntm = (M + 255) / 256, ntn = N / 128, per = (K / 64 + splits - 1) / splits;
   const bf16* nullb = nullptr;
   bf16* ws = (bf16*)workspace;
@@ -271,7 +279,8 @@ int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16*
   void* args[] = {(void*)&x, (void*)&w, (void*)&nullb, (void*)&ws, (void*)&nullb, (void*)&nullb, (void*)&M, (void*)&N, (void*)&K,
                   (void*)&ldx, (void*)&ldw, (void*)&flen, (void*)&zero, (void*)&ntm, (void*)&ntn, (void*)&gm,
                   (void*)&nov, (void*)&per, (void*)&zero, (void*)&zero, (void*)&zero, (void*)&zero};
-  (void)hipLaunchKernel((const void*)gemm_asm_128_partial, dim3(ntm * ntn * splits), dim3(256), args, (size_t)lds, s);
+  if (hipLaunchKernel((const void*)gemm_asm_128_partial, dim3(ntm * ntn * splits), dim3(256), args, (size_t)lds, s) != hipSuccess)
+    return ll_check_launch("gemm_asm_128_partial");
   const long long threads = (long long)M * (N / 8);
   dim3 grid((unsigned)((threads + 255) / 256)), block(256);
   if (norm_w != nullptr)       // (the caller checked: bias + residual, N <= 4096)
@@ -289,24 +298,17 @@ int gemm_asm_ksplit_launch(const bf16* x, const bf16* w, const bf16* bias, bf16*
 // in its order, so the results are bit-identical to the HIP W8A8 kernels.  1 = launched, 0 = not covered.
 int gemm_asm_launch_i8(const int8_t* x, const int8_t* w, bf16* out, int M, int N, int K, int ldo, int epilogue, const EpiArgs& ea,
                        int gm, hipStream_t s) {
-  if (ea.sx == nullptr || ea.sw == nullptr || ea.mod != nullptr || M <= 0 || K % 128 != 0 || K < 512) return 0;
-  if (epilogue == LL_EPI_BIAS_GATE_RES && ea.frame_len <= 0) return 0;
-  if ((long long)256 * K >= 0x7fffffffLL) return 0;
+  if (ea.sx == nullptr || ea.sw == nullptr) return 0;
   const bool has_v = ea.v_out != nullptr;
-  int wn = 0;
-  if (has_v) wn = (ea.v_L == M && ea.v_col0 % 192 == 0 && ea.v_C > 0 && epilogue == LL_EPI_BIAS && N % 192 == 0) ? 192 : 0;
-  else if (epilogue == LL_EPI_BIAS_GELU) wn = N % 224 == 0 ? 224 : 0;
-  else if (epilogue == LL_EPI_BIAS && N > 2048 && N % 192 == 0) wn = 192;
-  else if (N % 128 == 0 && N <= 2048) wn = 128;
+  const int wn = gemm_asm_width_i8(M, N, K, epilogue, ea.mod == nullptr, has_v, has_v && ea.v_L == M && ea.v_col0 % 192 == 0 && ea.v_C > 0,
+                                   ea.frame_len);
   if (!wn) return 0;
   const void* fn = wn == 224 ? (const void*)gemm_asmq_224_gelu
                    : wn == 192 ? (const void*)gemm_asmq_192_bias
                    : epilogue == LL_EPI_BIAS ? (const void*)gemm_asmq_128_bias
                    : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asmq_128_gate_res : (const void*)gemm_asmq_128_res;
-  static bool attr[4] = {false, false, false, false};
-  const int slot = wn == 224 ? 0 : wn == 192 ? 1 : epilogue == LL_EPI_BIAS ? 2 : 3;      // (gate_res / res share the 128-wide LDS size)
   const int lds = 3 * wn * 128 + 4 * 2 * 8192;
-  if (!attr[slot] || slot == 3) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr[slot] = true; }
+  if (int rc = ll_lds_attr(fn, lds)) return rc;
   const int ntm = (M + 255) / 256, ntn = N / wn;
   const bf16* gate = epilogue == LL_EPI_BIAS_GATE_RES ? ea.e + (size_t)ea.gate_idx * N : nullptr;
   const int gstride = ea.nmod * N * 2;
@@ -316,6 +318,6 @@ int gemm_asm_launch_i8(const int8_t* x, const int8_t* w, bf16* out, int M, int N
   void* args[] = {(void*)&x, (void*)&w, (void*)&ea.bias, (void*)&out, (void*)&ea.res, (void*)&gate, (void*)&M, (void*)&N, (void*)&K,
                   (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm,
                   (void*)&v_out, (void*)&v_col0, (void*)&v_C, (void*)&v_shift, (void*)&v_lo, (void*)&v_hi, (void*)&ea.sx, (void*)&ea.sw};
-  (void)hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s);
+  if (hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s) != hipSuccess) return ll_check_launch("gemm_asm");
   return 1;
 }

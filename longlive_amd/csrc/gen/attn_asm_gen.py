@@ -51,7 +51,60 @@ DIAG = False                                 # diagnostic build only (tools/attn
                                              # tile, summed per wave and stored to a debug buffer (s[56:57] + 32 * (4 * s58 + wave)); never in the library
 S_DBG, S_WG = 56, 58
 import os as _os
-KNOB = lambda name, default: type(default)(_os.environ.get("ASM_" + name, default))    # schedule experiments (tools/attn_asm_diag)
+
+# ---- schedule / timing knobs (environment ASM_<name>, ASM_G_<name> for the GEMM generator) ---------------------------------
+# Two kinds.  Schedule knobs (VF_LEAD, FIN_SPAN, ...) move instructions and keep the results valid; the ones in effect are recorded
+# in KNOBS_SET and travel into the library's ll_*_plan strings (knobs_header).  TIMING-ONLY knobs (NO_*: a part of the loop is
+# removed, the results are INVALID) are refused unless the generator was started with --diag (tools/build_diag_variants.sh,
+# tools/build_gemm_variant.sh) or a tool called allow_diag_knobs(): a variable left over in a shell can never build a wrong kernel
+# into the shipped library.  The Makefile runs the generators in an EMPTY environment on top of that.
+DIAG_KNOBS_OK = "--diag" in sys.argv
+KNOBS_SET = {}
+
+
+def allow_diag_knobs(ok=True):
+    global DIAG_KNOBS_OK
+    DIAG_KNOBS_OK = ok
+
+
+def knob_env(prefix, name, default):
+    raw = _os.environ.get(prefix + name)
+    if raw is None:
+        return default
+    val = type(default)(raw)
+    if val == default:
+        return default
+    if name.startswith("NO_") and not DIAG_KNOBS_OK:
+        raise SystemExit(f"{prefix}{name}={raw}: timing-only knob (results invalid) refused without --diag; "
+                         f"unset it, or build a diagnostic variant with tools/build_diag_variants.sh / tools/build_gemm_variant.sh")
+    KNOBS_SET[prefix + name] = raw
+    return val
+
+
+def KNOB(name, default):
+    return knob_env("ASM_", name, default)
+
+
+def knobs_string():
+    """'' for the default schedule, else 'NAME=value,...#crc' of every ASM_* / ASM_G_* variable of this environment that a generator
+    would honour (the names are taken from the environment: both generators read theirs lazily)."""
+    import zlib
+    items = sorted((k, v) for k, v in _os.environ.items() if k.startswith("ASM_") and v not in ("", "0"))
+    if not items:
+        return ""
+    txt = ",".join(f"{k}={v}" for k, v in items)
+    return f"{txt}#{zlib.crc32(txt.encode()) & 0xffffffff:08x}"
+
+
+def knobs_header(path):
+    ks = knobs_string()
+    bad = [k for k in ks.split("#")[0].split(",") if "_NO_" in k.split("=")[0]] if ks else []
+    if bad and not DIAG_KNOBS_OK:
+        raise SystemExit(f"{bad}: timing-only knobs refused without --diag")
+    open(path, "w").write("// generated by gen/attn_asm_gen.py --knobs-header: the generator knobs this library was built with\n"
+                          f"#define LL_ASM_KNOBS \"{ks}\"\n")
+
+
 LSUM = KNOB("LSUM", 0)                       # 1: row sums by the matrix pipe (ones-MFMA into LACC); 0: by v_add_f32 into 4 partials per q-block
 ADD_LATE = KNOB("ADD_LATE", 0)               # LSUM = 0: the adds of the elements whose registers survive the in-place pack (registers
                                              # 8..15 of every score tile) are issued in phase B instead of phase A
@@ -845,6 +898,9 @@ if __name__ == "__main__":
     diag = "--diag" in sys.argv
     if diag:
         sys.argv.remove("--diag")
+    if "--knobs-header" in sys.argv:
+        knobs_header(sys.argv[sys.argv.index("--knobs-header") + 1])
+        sys.exit(0)
     if "--dma" in sys.argv:
         k = sys.argv.index("--dma")
         mode = sys.argv[k + 1]

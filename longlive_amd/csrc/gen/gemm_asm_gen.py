@@ -32,6 +32,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import attn_asm_gen as _A                                                                     # noqa: E402
 from attn_asm_gen import Gen, finalize, lint, sreg, vreg, areg, to_inc, f32bits, spread   # noqa: E402
 
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_RES = 0, 1, 2, 3
@@ -57,8 +58,9 @@ S_XM0 = 30                                                        # LDS base of 
 
 
 def KN(k):
-    """timing-only experiment switches (ASM_G_<k>=1; results are invalid with any of them set)"""
-    return int(os.environ.get("ASM_G_" + k, "0"))
+    """timing-only experiment switches (ASM_G_<k>=1; results are invalid with any of them set): refused without --diag
+    (attn_asm_gen.knob_env)"""
+    return _A.knob_env("ASM_G_", k, 0)
 
 
 class Cfg:
@@ -550,6 +552,8 @@ def gen_epilogue(g: Gen, c: Cfg):
 
 
 if __name__ == "__main__":
+    if "--diag" in sys.argv:
+        sys.argv.remove("--diag")                                            # (attn_asm_gen saw it at import: timing-only knobs allowed)
     WN, epi = int(sys.argv[1]), int(sys.argv[2])
     i8 = len(sys.argv) > 5 and sys.argv[5] == "i8"
     txt = generate(WN, epi, f"GA{WN}E{epi}" + ("I8" if i8 else ""), i8)

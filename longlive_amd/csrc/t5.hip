@@ -206,10 +206,8 @@ extern "C" int ll_t5_attention(const ll_bf16* q, const ll_bf16* k, const ll_bf16
 #define T5_LAUNCH(LT)                                                                                                  \
   do {                                                                                                                 \
     size_t lds = (size_t)(64 * LT) * 128 + 64 * (64 * LT + 8) * 2 + (2 * 64 * LT) * 2;                                 \
-    static bool attr = false;                                                                                          \
-    if (!attr) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void*)t5_attn_kernel<LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr = true;                                                                                                     \
+    {                                                                                          \
+      (void)ll_lds_attr((const void*)t5_attn_kernel<LT>, (int)lds); \
     }                                                                                                                  \
     hipLaunchKernelGGL((t5_attn_kernel<LT>), grid, block, lds, s, (const bf16*)q, (const bf16*)k, ldqk, (const bf16*)vt, \
                        (const bf16*)bias_tab, (bf16*)out, ldo, seq_len);                                               \

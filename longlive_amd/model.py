@@ -359,7 +359,9 @@ class CausalWanModelHIP(nn.Module):
         h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 3, 4, F, c.eps)
         ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
         self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs, splitk=self.ffn2_splitk)
+                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs,
+                  splitk=self.ffn2_splitk and mod is None)      # a per-batch modulation vector is not covered by the generated kernel: such a
+                                                                # call would reach the split-K hand-off kernel, whose status only blocking callers poll
         return plan
 
     # ---- forward -----------------------------------------------------------------------------------------------

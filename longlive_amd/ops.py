@@ -249,8 +249,11 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
             assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
-    if not splitk and M * N <= (1 << 22) and epilogue in (EPI_BIAS, EPI_BIAS_RES) and _ksplit_plan(lib, M, N, K):
-        # few rows (the text side: umT5 at 512 tokens, text K / V projections): K cut into ranges so that the grid fills the device
+    if not splitk and M <= 1024 and M * N <= (1 << 22) and epilogue in (EPI_BIAS, EPI_BIAS_RES) and _ksplit_plan(lib, M, N, K):
+        # few rows (the text side: umT5 at 512 tokens, text K / V projections): K cut into ranges so that the grid fills the device.
+        # Taken by itself only up to 1024 rows: the DiT's own linears (a 1-frame chunk has M = 1560) never come here, so the order
+        # of a row's fp32 sum there does not depend on M or on the device's CU count.  Inside this region the number of ranges
+        # depends on N and K only (gemm_ksplit_splits); WHETHER the path is taken still depends on M and the CU count.
         ws = ksplit_workspace(x.device, M, N, K)
         _lib.check(lib.ll_gemm_bf16_ksplit(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                            _ptr(res), ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_bf16_ksplit")
@@ -277,10 +280,14 @@ def _ksplit_plan(lib, M: int, N: int, K: int) -> int:
     return int(lib.ll_gemm_ksplit_plan(M, N, K))
 
 
+def _dev_index(device) -> int:
+    return torch.cuda.current_device() if device.index is None else device.index
+
+
 def ksplit_workspace(device, M: int, N: int, K: int) -> torch.Tensor:
     """Scratch for ll_gemm_bf16_ksplit ([splits][M][N] fp32 tile sums; needs no initialisation), one buffer per (device, stream)."""
     need = int(_lib.load().ll_gemm_ksplit_workspace_bytes(M, N, K))
-    key = (device.type, device.index, int(_stream() or 0))
+    key = (device.type, _dev_index(device), int(_stream() or 0))
     buf = _ksplit_ws.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
@@ -293,12 +300,13 @@ def splitk_workspace(device, M: int, N: int) -> torch.Tensor:
     to the launches of one stream at a time (two streams may run the same projection concurrently: overlap_context)."""
     lib = _lib.load()
     need = int(lib.ll_gemm_splitk_workspace_bytes(M, N))
-    key = (device.type, device.index, int(_stream() or 0))
-    buf = _splitk_ws.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.zeros(max(need, 16), dtype=torch.uint8, device=device)
-        _splitk_ws[key] = buf
-    return buf
+    st = torch.cuda.current_stream(device)
+    key = (device.type, _dev_index(device), int(st.cuda_stream or 0))
+    ent = _splitk_ws.get(key)
+    if ent is None or ent[0].numel() < need:
+        ent = (torch.zeros(max(need, 16), dtype=torch.uint8, device=device), st)      # the Stream object is kept: its handle stays valid
+        _splitk_ws[key] = ent
+    return ent[0]
 
 
 def splitk_check() -> None:
@@ -310,12 +318,11 @@ def splitk_check() -> None:
     import ctypes as C
     lib = _lib.load()
     bad = []
-    for key, buf in list(_splitk_ws.items()):
+    for key, (buf, stream) in list(_splitk_ws.items()):
         st = C.c_uint(0)
         with torch.cuda.device(buf.device):
-            _lib.check(lib.ll_gemm_splitk_status(buf.data_ptr(), C.addressof(st), key[2] or None), "ll_gemm_splitk_status")
-        if st.value:
-            buf[:4096].zero_()                # flags carry epochs (stale words never match); start from a clean page anyway
+            _lib.check(lib.ll_gemm_splitk_status(buf.data_ptr(), C.addressof(st), stream.cuda_stream or None), "ll_gemm_splitk_status")
+        if st.value:                          # (flags carry per-launch epochs: stale words never match, nothing needs clearing)
             bad.append((key, st.value))
     if bad:
         raise RuntimeError(f"split-K GEMM hand-off timed out (workspace, launch epoch): {bad}; the outputs of those launches are invalid")
@@ -445,7 +452,7 @@ def attn_workspace(device) -> Optional[torch.Tensor]:
     need = int(lib.ll_flash_attn_workspace_bytes())
     if need == 0:
         return None
-    key = (device.type, device.index, int(_stream() or 0))
+    key = (device.type, _dev_index(device), int(_stream() or 0))
     buf = _attn_ws.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=device)

@@ -171,6 +171,7 @@ class CausalInferencePipeline(nn.Module):
             self._clean_context_pass(denoised, cond, start)
             yield start, denoised
         self._join_context()
+        _ops.splitk_check()           # end of the stream (blocking): a split-K hand-off that timed out anywhere in it raises here
 
     @torch.no_grad()
     def stream_video(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None,

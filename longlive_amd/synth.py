@@ -23,6 +23,7 @@ from typing import Dict, Tuple
 import torch
 
 _M64 = (1 << 64) - 1
+FORCE_TORCH_HASH = False       # tests: evaluate the hash with int64 tensor ops on the GPU too (the path ll_synth_hash replaces)
 
 
 def _s64(x: int) -> int:
@@ -55,11 +56,24 @@ def _counter(numel: int, device) -> torch.Tensor:
     return torch.arange(numel, dtype=torch.int64, device=device)
 
 
+def _device_hash(kind: int, s: int, numel: int, device) -> torch.Tensor:
+    """The same integers from the library's hash kernel (ll_synth_hash, csrc/synth_hash.h): on a GPU no int64 tensor op is issued
+    (a python process under `rocprofv3 --pmc` dies in torch's int64 elementwise kernels on this image; with this, bench.py is
+    profilable) and generation is one launch instead of ~40 per chunk."""
+    from . import _lib
+    out = torch.empty(numel, dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().ll_synth_hash(out.data_ptr(), 0, numel, s & _M64, kind, torch.cuda.current_stream().cuda_stream), "ll_synth_hash")
+    return out
+
+
 def hash_uniform(seed: int, name: str, shape, device="cpu", chunk: int = 1 << 26) -> torch.Tensor:
     """float32 uniform in [0, 1) with 24 exact bits."""
     numel = int(math.prod(shape))
-    out = torch.empty(numel, dtype=torch.float32, device=device)
     s = _stream(seed, name)
+    if torch.device(device).type == "cuda" and not FORCE_TORCH_HASH:
+        return _device_hash(0, s, numel, device).view(*shape)
+    out = torch.empty(numel, dtype=torch.float32, device=device)
     for lo in range(0, numel, chunk):
         hi = min(numel, lo + chunk)
         idx = torch.arange(lo, hi, dtype=torch.int64, device=device)
@@ -71,8 +85,10 @@ def hash_uniform(seed: int, name: str, shape, device="cpu", chunk: int = 1 << 26
 def hash_normal(seed: int, name: str, shape, device="cpu", chunk: int = 1 << 25) -> torch.Tensor:
     """float32 approx. N(0,1): Irwin-Hall sum of 12 uniforms of 16 bits (exact integer sum)."""
     numel = int(math.prod(shape))
-    out = torch.empty(numel, dtype=torch.float32, device=device)
     s = _stream(seed, name)
+    if torch.device(device).type == "cuda" and not FORCE_TORCH_HASH:
+        return _device_hash(1, s, numel, device).view(*shape)
+    out = torch.empty(numel, dtype=torch.float32, device=device)
     for lo in range(0, numel, chunk):
         hi = min(numel, lo + chunk)
         idx = torch.arange(lo, hi, dtype=torch.int64, device=device)

@@ -788,3 +788,19 @@ def test_gemm_w8a8_splitk_is_exact(ops):
         got = ops.gemm_w8a8(xq, sx, wq, sw, b, ops.EPI_BIAS_GATE_RES, splitk=True, **kw)
         assert torch.equal(got, want)
     torch.cuda.synchronize()
+
+
+def test_synth_hash_kernel_matches_the_tensor_hash():
+    """ll_synth_hash (the integer hash as one kernel of the library) against the int64 tensor evaluation it replaces on the GPU and
+    against the CPU evaluation: bit-identical, any length (ragged last workgroup), both kinds."""
+    try:
+        for seed, name, shape in ((0, "blocks.3.ffn.0.weight", (257, 33)), (9, "noise", (5, 16, 7, 11)), (2, "x", (1,))):
+            for fn in (synth.hash_uniform, synth.hash_normal):
+                synth.FORCE_TORCH_HASH = False
+                got = fn(seed, name, shape, device=DEV)
+                synth.FORCE_TORCH_HASH = True
+                ref_dev = fn(seed, name, shape, device=DEV)
+                ref_cpu = fn(seed, name, shape)
+                assert got.shape == ref_cpu.shape and torch.equal(got, ref_dev) and torch.equal(got.cpu(), ref_cpu), (seed, name, fn.__name__)
+    finally:
+        synth.FORCE_TORCH_HASH = False

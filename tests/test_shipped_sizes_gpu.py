@@ -78,13 +78,17 @@ def test_flash_attn_production_grids(Lq):
     # every element: a wrong (head, q-tile) mapping or a dropped key tile is an O(1) error, far above two kernels' rounding
     d = (got.float() - plain.float()).abs()
     assert d.max().item() < 8e-3, d.max().item()
+    # ... and relative to the SIGNAL: at 18720 keys the output's own standard deviation is ~0.7 / sqrt(18720 / e) = 8e-3, so the
+    # absolute bounds here are ~1 sigma; a dropped key tile (1 of 293) or a 1 % mis-scale is invisible to them but not to these
+    rel_plain = ((got.double() - plain.double()).norm() / plain.double().norm()).item()
+    assert rel_plain < 5e-3, rel_plain
     assert torch.equal(pipe, plain), "the ping-pong kernel and the plain one round identically"
     assert (sk.float() - plain.float()).abs().max().item() < 8e-3
     assert (m16.float() - plain.float()).abs().max().item() < 8e-3
     # sampled rows, exact: two rows of every (head, 256-row q-tile) workgroup, in different waves / lane halves; plus the
     # first and last rows
     nqt = (Lq + 255) // 256
-    worst = 0.0
+    worst = worst_rel = 0.0
     scale = 1.0 / math.sqrt(D)
     for h in range(H):
         rows = set()
@@ -97,7 +101,11 @@ def test_flash_attn_production_grids(Lq):
         ref = torch.softmax(s, dim=-1) @ v[0, :, h].double()
         err = (got[0, idx, h].double() - ref).abs().max().item()
         worst = max(worst, err)
-    print(f"Lq={Lq}: max abs err vs fp64 on sampled rows {worst:.2e}; vs plain kernel (all elements) {d.max().item():.2e}")
+        rel = ((got[0, idx, h].double() - ref).norm() / ref.norm()).item()
+        worst_rel = max(worst_rel, rel)
+        assert rel < 6e-3, (h, rel)            # per head, against exact arithmetic
+    print(f"Lq={Lq}: max abs err vs fp64 on sampled rows {worst:.2e}, worst per-head rel-L2 {worst_rel:.2e}; vs plain kernel (all elements) "
+          f"max abs {d.max().item():.2e}, rel-L2 {rel_plain:.2e}")
     assert worst < 1.2e-2, worst
 
 
@@ -331,6 +339,30 @@ def test_config3_60s_single_prompt_property(real30):
     # prefix property: the stream is causal, so the first 21 frames equal a 21-frame run bit for bit
     P2, lat2 = _long_run(gen, cfg, 21, None)
     assert torch.equal(lat[:, :21], lat2)
+
+
+def test_config4_interactive_full_length(real30):
+    """BASELINE config 4 at full length: 240 latent frames, 6 prompts, switches at 40 / 80 / 120 / 160 / 200
+    (configs/longlive_interactive_inference.yaml:21-27; global_sink = false), the KV-recache forward on every switch
+    (interactive_causal_inference.py:34-106).  ~11 s on one MI355X.  Switch frames that are not block starts take effect at the
+    block that contains them: blocks 14, 27, 40, 54, 67 (the reference's own rule, :258-262)."""
+    from longlive_amd.pipeline import InteractiveCausalInferencePipeline
+    cfg, gen = real30
+    T, sw = 240, [40, 80, 120, 160, 200]
+    prompts = {f"p{i}": {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + i, device=DEV)} for i in range(6)}
+    I = InteractiveCausalInferencePipeline(_pipe_args(global_sink=False), DEV, generator=gen, text_encoder=lambda text_prompts: prompts[text_prompts[0]])
+    I.randn_like = TD.HashRandn(47)
+    _, lat = I.inference(synth.synth_noise(cfg, T, seed=0, device=DEV), text_prompts_list=[[f"p{i}"] for i in range(6)],
+                         switch_frame_indices=sw, return_latents=True, profile=True)
+    pr = I.last_profile
+    assert list(pr["switch_blocks"]) == [14, 27, 40, 54, 67], pr["switch_blocks"]
+    fs = cfg.frame_seqlen
+    assert lat.shape == (1, T, 16, 60, 104) and torch.isfinite(lat.float()).all()
+    for c in (I.kv_cache1[0], I.kv_cache1[29]):
+        assert (c["global_end_index"], c["local_end_index"]) == (374400, 18720) == (T * fs, 12 * fs)
+    std = lat.float().std(dim=(0, 2, 3, 4))
+    assert 0.3 < float(std.min()) and float(std.max()) < 3.0, (float(std.min()), float(std.max()))
+    print(f"config 4: switch blocks {pr['switch_blocks']}, switch latencies {[round(x, 1) for x in (pr.get('switch_latency_ms') or [])]} ms")
 
 
 def test_config5_int8_long_run_property(real30):

@@ -10,10 +10,10 @@ clean() {
 }
 restore() {
   clean
-  env -u ASM_G_NO_MFMA -u ASM_G_NO_X -u ASM_G_NO_W -u ASM_G_NO_WREAD -u ASM_G_NO_EPI make -C longlive_amd/csrc -j6 > /dev/null 2>&1 || echo "WARNING: could not rebuild the in-tree library"
+  make -C longlive_amd/csrc -j6 > /dev/null 2>&1 || echo "WARNING: could not rebuild the in-tree library"      # (the Makefile runs the generators in an empty environment)
 }
 trap restore EXIT
 clean
-env "$@" make -C longlive_amd/csrc -j6 2>&1 | grep -E " error|lint findings" | grep -v " 0 lint" || true
+make -C longlive_amd/csrc -j6 GENENV="$*" GENFLAGS=--diag 2>&1 | grep -E " error|lint findings" | grep -v " 0 lint" || true
 mkdir -p experiments/r03/libs/$name
 cp longlive_amd/liblonglive_hip.so experiments/r03/libs/$name/liblonglive_hip.so

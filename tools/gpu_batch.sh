@@ -1,0 +1,85 @@
+#!/bin/bash
+# One parametrised script for everything that is run ON the GPU box (replaces round 3's per-call tools/runs/r03*.sh files):
+#   bash tools/gpu_batch.sh <outdir-name> step [step ...]
+# writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
+# joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
+#   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | bench | bench_short | trace | pmc_bench | pmc_inpipe
+#   layerseq[=N] | layerexp | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
+set -u
+cd "$(dirname "$0")/.." || exit 1
+O=gpurun_out/$1; shift
+mkdir -p $O
+export TMPDIR=/tmp
+dead() { [ $1 -eq 124 ] || [ $1 -eq 137 ] || [ $1 -eq 134 ] || [ $1 -eq 139 ]; }
+benchline() {
+python3 - "$1" <<'PY'
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print("no bench line:", e); sys.exit(0)
+t = r.get("telemetry") or {}
+g = t.get("gpu_metrics_delta") or {}
+print(f"{r['value']:.2f} {r['unit']}  ms/step {r['ms_per_step']:.2f}  roofline frac {r['roofline']['frac']:.4f} avg_us {r['roofline'].get('avg_us', 0):.1f}  "
+      f"sclk {t.get('sclk_mhz_avg', 0):.0f} MHz  power {t.get('power_w_avg', 0):.0f} W  ppt {g.get('ppt_residency_acc', 0) / max(1, g.get('accumulation_counter', 1)):.2f}")
+PY
+}
+for step in "$@"; do
+  name=${step%%=*}; arg=""; [ "$name" != "$step" ] && arg=${step#*=}
+  echo "== $step"
+  case $name in
+    smoke)
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; rc=$?; echo "smoke rc=$rc"; tail -1 $O/smoke.log ;;
+    tests)
+      if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -q -x -k "$arg" > $O/gputests.log 2>&1; else timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; fi
+      rc=$?; echo "pytest rc=$rc"; tail -5 $O/gputests.log; [ $rc -ne 0 ] && { cp $O/gputests.log $O/FAILED_gputests.log; grep -E "^(FAILED|ERROR)|Error|fault" $O/gputests.log | head -20; } ;;
+    testfile)
+      f=${arg%%::*}; k=""; [ "$f" != "$arg" ] && k=${arg#*::}
+      if [ -n "$k" ]; then timeout -k 10 900 python -m pytest $f -m gpu -q -x -s -k "$k" > $O/test_$(basename $f .py).log 2>&1; else timeout -k 10 900 python -m pytest $f -m gpu -q -x -s > $O/test_$(basename $f .py).log 2>&1; fi
+      rc=$?; echo "pytest rc=$rc"; tail -6 $O/test_$(basename $f .py).log ;;
+    bench)
+      timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; rc=$?; echo "bench rc=$rc"; benchline $O/bench.json ;;
+    bench_short)
+      timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/bench_short.json 2> $O/bench_short.err; rc=$?; benchline $O/bench_short.json ;;
+    trace)
+      timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/trace.log 2>&1; rc=$?; echo "trace rc=$rc"
+      T=$(ls $O/trace/*/*kernel_trace.csv 2>/dev/null | head -1); [ -n "$T" ] && python tools/prof_summary.py $T --blocks 2 > $O/kernel_summary.md 2>$O/prof_summary.err && head -30 $O/kernel_summary.md | cut -c1-200
+      S=$(ls $O/trace/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp $S $O/kernel_stats.csv
+      rm -f $O/trace/*/*kernel_trace.csv $O/trace/*/*.db ;;
+    pmc_bench)      # ONE counter pass over bench.py itself, the program directly after `--`; if it dies the log is kept and nothing is retried
+      timeout -k 10 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_bench -- python3 bench.py --steps 2 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/pmc_bench.log 2>&1; rc=$?
+      echo "pmc_bench rc=$rc"; tail -3 $O/pmc_bench.log | cut -c1-300
+      C=$(ls $O/pmc_bench/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$C" ] && python tools/pmc_bench_summary.py $C > $O/pmc_bench.md 2> $O/pmc_bench_summary.err && cat $O/pmc_bench.md | cut -c1-200
+      find $O/pmc_bench -name "*.db" -delete 2>/dev/null
+      [ $rc -eq 139 ] && { echo "rocprofv3 --pmc over bench.py crashed again (log kept: $O/pmc_bench.log); not retried"; rc=0; } ;;
+    pmc_inpipe)
+      bash tools/pmc_inpipe.sh $O/pmc > $O/pmc.log 2>&1; rc=$?; tail -8 $O/pmc.log
+      python tools/pmc_inpipe_summary.py $O/pmc --md $O/pmc_inpipe.md --json $O/pmc_inpipe.json > /dev/null 2> $O/pmc_summary.err; grep "^|" $O/pmc_inpipe.md | cut -c1-220
+      find $O/pmc -name "*.db" -delete ;;
+    layerseq)
+      timeout -k 10 200 ./tools/kbench layerseq ${arg:-1500} 2>&1 | tee -a $O/layerseq.txt; rc=${PIPESTATUS[0]} ;;
+    layerexp)      # timing-only: what removing a launch / balancing the attention grid could buy (tools/kbench.hip layerseq switches)
+      rc=0
+      for rep in 1 2; do
+        for e in "" "KB_SKIP=7" "KB_SKIP=2" "KB_SKIP=5" "KB_SKIP=0,10" "KB_SKIP=8" "KB_ATTN_LQ=5376 KB_ATTN_S=17024" "KB_ATTN_LQ=5376 KB_ATTN_S=18752" "KB_SKIP=3"; do
+          echo "-- [$e]"; env $e timeout -k 10 120 ./tools/kbench layerseq 900 2>&1 | grep -v "^$"; r=${PIPESTATUS[0]}; dead $r && { rc=$r; break 2; }
+        done
+      done | tee $O/layerexp.txt ;;
+    ab)
+      a=$(echo "$arg" | cut -d/ -f1); b=$(echo "$arg" | cut -d/ -f2); n=$(echo "$arg" | cut -d/ -f3); n=${n:-2}; rc=0
+      for i in $(seq 1 $n); do for t in "$a" "$b"; do
+        LL_TUNING=$t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/ab_$i.json 2> $O/ab_$i.err; rc=$?; dead $rc && break 2
+        echo -n "[$t] "; benchline $O/ab_$i.json
+      done; done | tee -a $O/ab.txt ;;
+    abseq)
+      a=$(echo "$arg" | cut -d/ -f1); b=$(echo "$arg" | cut -d/ -f2); rc=0
+      for i in 1 2 3; do for t in "$a" "$b"; do echo -n "[$t] "; LL_TUNING=$t timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break 2; }; done; done | tee -a $O/abseq.txt ;;
+    kbench)
+      timeout -k 10 300 ./tools/kbench $arg 2>&1 | tee -a $O/kbench.txt; rc=${PIPESTATUS[0]} ;;
+    configs)
+      timeout -k 10 400 python tools/run_configs.py 240 > $O/configs34.json 2>$O/configs.err; rc=$?; echo "rc=$rc"; head -c 900 $O/configs34.json; echo ;;
+    *) echo "unknown step $step"; rc=1 ;;
+  esac
+  if dead $rc; then echo "step $step died (rc $rc): batch stopped"; exit $rc; fi
+done
+echo "done"

@@ -309,21 +309,34 @@ static void bench_layerseq(int layers) {
   void* skws; CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb));
   const float scale = 1.0f / sqrtf(128.f);
   ensure_ws();
+  // TIMING-ONLY experiment switches (what a fusion or a balanced grid could buy, before building it):
+  //   KB_SKIP=i,j,...   leave launches i, j, ... (0-based, model order) out of the layer
+  //   KB_ATTN_LQ / KB_ATTN_S   geometry of the self-attention launch (e.g. 5376 rows x 17024 keys = 252 workgroups x 266 key tiles:
+  //                     the grid a key-split that balances 228 workgroups x 293 tiles over 256 CUs would run, without its merge)
+  unsigned skip = 0;
+  if (const char* sk = getenv("KB_SKIP")) for (const char* p = sk; *p; ++p) { if (*p >= '0' && *p <= '9') { int v = atoi(p); skip |= 1u << v; while (*p >= '0' && *p <= '9') ++p; if (!*p) break; } }
+  const int aLq = getenv("KB_ATTN_LQ") ? atoi(getenv("KB_ATTN_LQ")) : L, aS = getenv("KB_ATTN_S") ? atoi(getenv("KB_ATTN_S")) : S;
+  Buf qbig((size_t)(aLq > L ? aLq : 1) * C, 1.0f), obig((size_t)(aLq > L ? aLq : 1) * C, 0.f);
+  uint16_t* aq = aLq > L ? qbig.d : q.d;
+  uint16_t* ao = aLq > L ? obig.d : att.d;
+  if (skip || aLq != L || aS != S) printf("layerseq: TIMING-ONLY experiment (skip mask 0x%x, self-attention %d rows x %d keys)\n", skip, aLq, aS);
+#define ON(i) (!(skip & (1u << (i))))
   auto layer = [&]() {
-    LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 0, 1, 1, L, C, 3, 1e-6f, s));
-    LL(ll_gemm_bf16_qkv(h.d, wqkv.d, bqkv.d, qkv.d, L, 3 * C, C, C, 3 * C, vc.d, 1, L, S, S - L, 0, L, s));
-    LL(ll_qk_norm_rope_kv_store(qkv.d, nw.d, nw.d, rf, rhw, q.d, kc.d, nullptr, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
-    LL(ll_flash_attn(q.d, kc.d, vc.d, att.d, 1, L, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, g_ws, g_ws_bytes, s));
-    LL(ll_gemm_bf16(att.d, wo.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 2, L, FS, s));
-    LL(ll_layernorm_affine(xs.d, nw.d, nb.d, h.d, L, C, 1e-6f, s));
-    LL(ll_gemm_bf16(h.d, wcq.d, bo.d, q.d, L, C, C, C, C, LL_EPI_BIAS, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
-    LL(ll_rmsnorm(q.d, nw.d, q.d, L, C, C, C, 1e-6f, s));
-    LL(ll_flash_attn(q.d, ck.d, cv.d, att.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, g_ws, g_ws_bytes, s));
-    LL(ll_gemm_bf16(att.d, wco.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_RES, xs.d, nullptr, nullptr, 0, 0, 0, 0, s));
-    LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 3, 4, 1, L, C, 3, 1e-6f, s));
-    LL(ll_gemm_bf16(h.d, w1.d, b1.d, ffh.d, L, F1, C, C, F1, LL_EPI_BIAS_GELU, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
-    LL(ll_gemm_bf16_splitk(ffh.d, w2.d, b2.d, xs.d, L, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 5, L, FS, skws, skb, s));
+    if (ON(0)) LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 0, 1, 1, L, C, 3, 1e-6f, s));
+    if (ON(1)) LL(ll_gemm_bf16_qkv(h.d, wqkv.d, bqkv.d, qkv.d, L, 3 * C, C, C, 3 * C, vc.d, 1, L, S, S - L, 0, L, s));
+    if (ON(2)) LL(ll_qk_norm_rope_kv_store(qkv.d, nw.d, nw.d, rf, rhw, q.d, kc.d, nullptr, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
+    if (ON(3)) LL(ll_flash_attn(aq, kc.d, vc.d, ao, 1, aLq, H, C, C, C, (long long)S * C, 0, aS, 0, 0, scale, g_ws, g_ws_bytes, s));
+    if (ON(4)) LL(ll_gemm_bf16(att.d, wo.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 2, L, FS, s));
+    if (ON(5)) LL(ll_layernorm_affine(xs.d, nw.d, nb.d, h.d, L, C, 1e-6f, s));
+    if (ON(6)) LL(ll_gemm_bf16(h.d, wcq.d, bo.d, q.d, L, C, C, C, C, LL_EPI_BIAS, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+    if (ON(7)) LL(ll_rmsnorm(q.d, nw.d, q.d, L, C, C, C, 1e-6f, s));
+    if (ON(8)) LL(ll_flash_attn(q.d, ck.d, cv.d, att.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, g_ws, g_ws_bytes, s));
+    if (ON(9)) LL(ll_gemm_bf16(att.d, wco.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_RES, xs.d, nullptr, nullptr, 0, 0, 0, 0, s));
+    if (ON(10)) LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 3, 4, 1, L, C, 3, 1e-6f, s));
+    if (ON(11)) LL(ll_gemm_bf16(h.d, w1.d, b1.d, ffh.d, L, F1, C, C, F1, LL_EPI_BIAS_GELU, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+    if (ON(12)) LL(ll_gemm_bf16_splitk(ffh.d, w2.d, b2.d, xs.d, L, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 5, L, FS, skws, skb, s));
   };
+#undef ON
   for (int i = 0; i < 3; ++i) layer();
   CK(hipStreamSynchronize(s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
