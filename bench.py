@@ -336,7 +336,7 @@ def _plan_text(fn, *a):
     return buf.value.decode()
 
 
-def kernel_table(summary, quant, splitk=False, mod_table=True):
+def kernel_table(summary, quant, mod_table=True):
     """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac)."""
     from longlive_amd import _lib
     lib = _lib.load()
@@ -358,12 +358,11 @@ def kernel_table(summary, quant, splitk=False, mod_table=True):
             # plain: 2 = the fused QKV call (V redirect), 1 = an ordinary call, 0 = a per-batch modulation vector rides along
             # (gate-residual calls when the model runs with use_modulation_table = False: those take the HIP kernels)
             plain = 2 if tag == "gemm_qkv" else (0 if (epi == 2 and not mod_table) else 1)
-            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, plain,
-                              1 if (tag == "gemm_f2" and splitk and not i8) else 0)                              # int8: _lin drops split-K
+            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, plain)
         elif tag == "flash_attn_self":
-            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1, 1)
+            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1)
         elif tag == "flash_attn_cross":
-            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1, 1)
+            name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1)
         else:
             name = {"ln_modulate": "ln_modulate_kernel", "layernorm_affine": "layernorm_affine_kernel", "rmsnorm": "rmsnorm_kernel",
                     "qk_norm_rope_kv_store": "qk_norm_rope_kv_kernel", "kv_roll": "copy_rows_kernel",
@@ -554,8 +553,8 @@ def run_replica(args, rank, world, local_rank, sync):
     del sd
     quant = None if args.quant == "none" else args.quant
     gen.model.set_quant(quant)
-    if os.environ.get("LL_SPLITK") is not None:                        # kernel A/B only
-        gen.model.ffn2_splitk = os.environ["LL_SPLITK"] == "1"
+    if os.environ.get("LL_FUSE_QN") == "0":                            # kernel A/B only: cross-attention q RMSNorm as its own launch
+        gen.model.fuse_cross_qnorm = False
     if os.environ.get("LL_MODTAB") == "0":                             # kernel A/B only
         gen.model.use_modulation_table = False
     if os.environ.get("LL_FUSE_V") == "0":
@@ -592,7 +591,6 @@ def run_replica(args, rank, world, local_rank, sync):
     elapsed = time.perf_counter() - t0
     ops.timer = None
     telemetry = tele.stop(local_rank) if tele is not None else None
-    ops.splitk_check()                                                 # raises if a split-K hand-off timed out (invalid output)
     res = dict(frames=args.steps * 3 * PIXEL_FRAMES_PER_LATENT, elapsed=elapsed, roofline=None, kernels=None, extras=None,
                cpu_baseline=None, overlap_context=bool(pipe.overlap_context), telemetry=telemetry,
                visible=os.environ.get("HIP_VISIBLE_DEVICES"))
@@ -602,7 +600,7 @@ def run_replica(args, rank, world, local_rank, sync):
         s = ktimer.summary()["flash_attn_self"]
         achieved = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
         traffic, src = None, None
-        plan_now = _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1, 1)
+        plan_now = _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1)
         pmc = os.path.join(ROOT, "profiles", "r03_pmc_inpipe.json")   # counters of the SAME kernel in the pipeline's launch order
         if os.path.exists(pmc) and "flash_attn_asm_kernel" in plan_now:
             try:
@@ -631,8 +629,7 @@ def run_replica(args, rank, world, local_rank, sync):
             blk_ms = 1e3 * (time.perf_counter() - t0)
             summ = ops.timer.summary()
             ops.timer = None
-            rows = kernel_table(summ, quant, splitk=bool(getattr(gen.model, "ffn2_splitk", False)),
-                                mod_table=bool(getattr(gen.model, "use_modulation_table", True)))
+            rows = kernel_table(summ, quant, mod_table=bool(getattr(gen.model, "use_modulation_table", True)))
             res["kernels"] = {"note": "one untimed steady-state block, HIP events around every launch (adds ~2 us of gap per launch: "
                                       f"this block took {blk_ms:.1f} ms); shares are of the sum of kernel time",
                               "sum_kernel_ms": sum(r["total_ms"] for r in rows), "rows": rows}

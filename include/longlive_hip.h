@@ -43,28 +43,31 @@ enum ll_epilogue {
 int ll_version(void);
 const char* ll_last_error(void);
 /* Development knob for A/B timing of kernel variants (tools/kbench, tools/kenergy, LL_TUNING=key=value,... for bench.py);
- * the defaults are the shipped configuration.  Keys: "gemm_variant" 0 = auto (cost model), 2 = 256x128, 3 = 256x256,
- * 4 = 256x256 ping-pong, 5 = 256x192, 6 = 256x224;  "attn_variant" 0 = simple, 1 = software-pipelined, 2 = + ping-pong wave
- * groups for >= 1024 keys (default);  "attn_xcd" 0/1 = XCD-aware workgroup placement off/on;  "attn_sk_wgs" -1 = stream-K attention off
- * (default: measured slower at the power limit), 0 = on when it shortens the walk, N = force N workgroups;  "gemm_group_m" = m-tiles per group of the GEMM tile walk
- * (default 4; <= 1: N fastest);  "attn_asm" 1 (default) = the generated one-wave-per-SIMD self-attention kernel
- * (flash_attn_asm_kernel) for single key ranges of >= "attn_asm_min_keys" keys (default 512: self- and cross-attention), 0 = the HIP kernels;  "gemm_asm" bit 0 = the generated GEMM kernels
- * (gemm_asm_224_gelu: FFN1; gemm_asm_192_bias: QKV with its V-cache redirect; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual) where they cover the call,
- * bit 1 = also in place of the split-K kernel, bits 2 / 3 = leave the GELU / the 128-wide kernels out, bit 4 (16) = ll_gemm_w8a8 /
- * ll_gemm_w8a8_qkv on the generated W8A8 kernels too (bit-identical results; default 3; 0 = HIP kernels only);  "attn_mfma16" 1 = 16x16x32 MFMA variant of the HIP attention kernel (measured slower; A/B only);
- * "gemm_splitk_fault" 1 = test hook: the split-K partner never signals (exercises the bounded wait).
+ * the defaults are the shipped configuration; every key names a path some shipped call can take.  Keys:
+ *   "gemm_asm"  bit 0 = the generated one-wave-per-SIMD GEMM kernels where they cover the call (gemm_asm_224_gelu: FFN1;
+ *               gemm_asm_192_bias: QKV with its V-cache redirect; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual),
+ *               bits 2 / 3 = leave the GELU / the 128-wide kernels out, bit 4 (16) = ll_gemm_w8a8 / ll_gemm_w8a8_qkv on the
+ *               generated W8A8 kernels too (bit-identical results, measured slower end to end); default 3; 0 = HIP kernels only
+ *   "gemm_variant" / "gemm_variant_wide" (N >= 4096 only)  tile of the HIP kernels (int8, embeddings / head, gemm_asm = 0):
+ *               0 = auto (cost model), 2 = 256x128, 3 = 256x256, 5 = 256x192, 6 = 256x224
+ *   "gemm_group_m"  m-tiles per group of the GEMM tile walk (default 4; <= 1: N fastest);  "gemm_lds_epi" 0 / 1 / 2 = HIP epilogues
+ *               staged through LDS: none / all but GELU (default) / all
+ *   "attn_asm"  1 (default) = the generated attention kernel (flash_attn_asm_kernel) for single key ranges of at least
+ *               "attn_asm_min_keys" keys (default 512: self- and cross-attention), 0 = the HIP kernels
+ *   "attn_variant"  HIP attention: 0 = plain kernel, 1 = software-pipelined, 2 = + ping-pong wave groups from "attn_pp_min_keys"
+ *               keys on (default 2);  "attn_xcd" 0 / 1 = XCD-aware workgroup placement (default 1)
+ *   "conv_halo" 0 / 1 = halo-tile convolution kernel of the VAE decoder (default 1)
  * Unknown key: LL_ERR_INVALID_ARG. */
 int ll_set_tuning(const char* key, int value);
 /* Host-only introspection: the kernel instance + tile + grid that ll_gemm_bf16 / ll_gemm_w8a8 / ll_flash_attn would launch
  * for a shape under the current tuning, as text in out[cap] (bench.py's per-kernel table names kernels from here). */
 int ll_gemm_plan(int M, int N, int K, int int8, char* out, int cap);
 /* The same for a call whose epilogue is known (LL_EPI_*): names the generated one-wave-per-SIMD kernel (gemm_asm_*, tuning key
- * "gemm_asm") where ll_gemm_bf16 (splitk_call = 0) or ll_gemm_bf16_splitk with a workspace (splitk_call = 1) takes it, the
- * split-K kernel where that one runs, else ll_gemm_plan's text.  plain = 1: an ordinary call (no V-cache output, no per-batch
- * modulation vector); 2: the fused QKV call (ll_gemm_bf16_qkv, one batch element); 0: a call with a modulation vector. */
-int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int plain, int splitk_call, char* out, int cap);
-int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, int have_workspace, char* out,
-                       int cap);
+ * "gemm_asm") where ll_gemm_bf16 / ll_gemm_w8a8 takes it, else ll_gemm_plan's text.  plain = 1: an ordinary call (no V-cache
+ * output, no per-batch modulation vector); 2: the fused QKV call (ll_gemm_bf16_qkv, one batch element); 0: a call with a
+ * modulation vector. */
+int ll_gemm_plan_epi(int M, int N, int K, int int8, int epilogue, int plain, char* out, int cap);
+int ll_flash_attn_plan(int Lq, int H, int B, int seg0_len, int seg1_len, int seg_adjacent, char* out, int cap);
 
 /* ---- norms / modulation ------------------------------------------------------------------------------------- */
 
@@ -127,30 +130,6 @@ int ll_gemm_bf16(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf1
                  int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod, int nmod,
                  int gate_idx, int rows_per_batch, int frame_len, ll_stream stream);
 
-/* Split-K form of ll_gemm_bf16 for long-K, 1536-wide projections (ffn.2, wan/modules/causal_model.py:406-408,462-468): 256 x 256
- * tiles with K cut in two, the halves exchanged through `workspace` and reduced inside the kernel (gemm_kernel_v4sk), same fused
- * epilogues, same arguments.  Taken when ll_gemm_splitk_plan(M, N, K, 0) == 1 (N % 256 == 0, K % 128 == 0, K >= 1024 and the
- * 2 x ceil(M / 256) x (N / 256) workgroups fit the device in one round) and workspace != NULL; otherwise it IS ll_gemm_bf16.
- * workspace: >= ll_gemm_splitk_workspace_bytes(M, N) bytes of 16-byte-aligned device memory, zeroed ONCE by the caller before its
- * first use and used by the launches of one stream at a time.  Results equal ll_gemm_bf16's up to the order of the fp32
- * accumulation (two K-halves summed at the end); run to run they are bit-identical.
- * Fail-safe hand-off: the partner flags carry a per-launch epoch (stale words never match, nothing is reset) and the wait is
- * bounded (50 ms of real time): a partner workgroup that never arrives leaves the launch's epoch in the workspace's error word
- * and the kernel drains -- the output of that launch is invalid, the GPU is not hung.  ll_gemm_splitk_status (BLOCKING on
- * `stream`) returns that word in *status (0 = every hand-off so far completed) and clears it. */
-int ll_gemm_bf16_splitk(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, int M, int N, int K, int ldx,
-                        int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod, int nmod,
-                        int gate_idx, int rows_per_batch, int frame_len, void* workspace, long long workspace_bytes,
-                        ll_stream stream);
-long long ll_gemm_splitk_workspace_bytes(int M, int N);
-int ll_gemm_splitk_plan(int M, int N, int K, int int8);
-int ll_gemm_splitk_status(void* workspace, unsigned* status, ll_stream stream);
-/* ... and of ll_gemm_w8a8 (int32 partial sums: the exchange is exact, the result equals ll_gemm_w8a8's bit for bit). */
-int ll_gemm_w8a8_splitk(const int8_t* xq, const float* sx, const int8_t* wq, const float* sw, const ll_bf16* bias, ll_bf16* out,
-                        int M, int N, int K, int ldo, int epilogue, const ll_bf16* res, const ll_bf16* e, const ll_bf16* mod,
-                        int nmod, int gate_idx, int rows_per_batch, int frame_len, void* workspace, long long workspace_bytes,
-                        ll_stream stream);
-
 /* Small-M form of ll_gemm_bf16 for the 512-token linears of the text side (umT5 self-attention / FFN projections,
  * wan/modules/t5.py:65-117,134-160; the text K/V projections of cross-attention, wan/modules/model.py:183-188): a grid of
  * ceil(M / 256) x (N / 128) tiles fills a fraction of the device, so K is cut into ll_gemm_ksplit_plan(M, N, K) ranges (0 = not
@@ -202,16 +181,31 @@ int ll_linear_small(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_
  * ([seg0_start, +seg0_len) then [seg1_start, +seg1_len)): frame sink + sliding window of the KV cache, or the 512
  * text tokens for cross-attention.  Replaces attention()/flash_attention() (wan/modules/attention.py:43-197) and the
  * sink/window gather + cat (wan/modules/causal_model.py:331-360).
- *   q,out [B, Lq, H*128] with row strides ldq/ldo; k,v [B, Sk, H*128] with row stride ldk, batch stride Sk*ldk.
- *   workspace (optional, may be NULL): >= ll_flash_attn_workspace_bytes() bytes of 16-byte-aligned device scratch owned by
- *   the caller (the ABI never allocates).  Only read when the stream-K form is enabled (ll_set_tuning "attn_sk_wgs" >= 0): a
- *   long contiguous key range is then cut into equal runs of 64-key tiles over ALL CUs (a launch of 228 (head, q-tile) pairs
- *   otherwise leaves 28 of the 256 CUs idle) and split pairs are merged by a second small launch on the same stream.
- *   Contents need no initialisation. */
+ *   q,out [B, Lq, H*128] with row strides ldq/ldo; k,v [B, Sk, H*128] with row stride ldk, batch stride k_batch_stride.
+ *   A single key range of >= 512 keys runs the generated kernel (flash_attn_asm_kernel: 4 waves x 64 query rows, one wave per
+ *   SIMD), shorter or two-piece ranges the HIP kernels. */
 int ll_flash_attn(const ll_bf16* q, const ll_bf16* k, const ll_bf16* v, ll_bf16* out, int B, int Lq, int H, int ldq,
                   int ldo, int ldk, long long k_batch_stride, int seg0_start, int seg0_len, int seg1_start,
-                  int seg1_len, float scale, void* workspace, long long workspace_bytes, ll_stream stream);
-long long ll_flash_attn_workspace_bytes(void);
+                  int seg1_len, float scale, ll_stream stream);
+
+/* Cross-attention's q path with two launches fewer: `q = self.norm_q(self.q(x))` then attention over the text keys
+ * (wan/modules/model.py:172,189; WanRMSNorm :78-86 normalises over ALL H*128 channels of a row).
+ *   ll_gemm_bf16_ssq   = ll_gemm_bf16 with LL_EPI_BIAS that also writes ssq[N / 128][M] (fp32): per row and 128-column n-tile the
+ *                        sum of squares of the bf16 outputs (the projection's epilogue; fixed summation order).
+ *   ll_flash_attn_qnorm = ll_flash_attn over ONE key range whose Q prologue sums the planes in plane order, forms
+ *                        rsq(sum / C + eps) and applies bf16(bf16(x * rinv) * norm_w) -- WanRMSNorm's rounding points -- before its
+ *                        own scaling: the separate RMSNorm launch (and its 2 x 14.4 MB of traffic) disappears.
+ * Both exist only as generated gfx950 kernels: ll_gemm_ssq_planes (planes written, 0 = not covered) and ll_flash_attn_qnorm_ok
+ * (1 / 0) say whether a shape is covered under the current tuning; otherwise the caller runs ll_gemm_bf16 + ll_rmsnorm +
+ * ll_flash_attn (the entry points return LL_ERR_INVALID_ARG rather than fall back).  q [B, Lq, H*128] contiguous rows (ldq = H*128),
+ * ssq rows are b * Lq + l. */
+int ll_gemm_ssq_planes(int M, int N, int K);
+int ll_gemm_bf16_ssq(const ll_bf16* x, const ll_bf16* w, const ll_bf16* bias, ll_bf16* out, float* ssq, int M, int N, int K, int ldx,
+                     int ldo, ll_stream stream);
+int ll_flash_attn_qnorm_ok(int H, int nkeys);
+int ll_flash_attn_qnorm(const ll_bf16* q, const float* ssq, const ll_bf16* norm_w, float eps, const ll_bf16* k, const ll_bf16* v,
+                        ll_bf16* out, int B, int Lq, int H, int ldq, int ldo, int ldk, long long k_batch_stride, int key_start,
+                        int nkeys, float scale, ll_stream stream);
 
 /* ---- embeddings / head / scheduler ------------------------------------------------------------------------------ */
 

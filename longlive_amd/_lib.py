@@ -19,9 +19,8 @@ SIGNATURES = {
     "ll_last_error": [],
     "ll_set_tuning": [C.c_char_p, _i],
     "ll_gemm_plan": [_i, _i, _i, _i, C.c_char_p, _i],
-    "ll_gemm_plan_epi": [_i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
-    "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
-    "ll_flash_attn_workspace_bytes": [],
+    "ll_gemm_plan_epi": [_i, _i, _i, _i, _i, _i, C.c_char_p, _i],
+    "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, C.c_char_p, _i],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_modulation_table": [_p, _p, _p, _i, _i, _i, _i, _p],
     "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
@@ -31,27 +30,26 @@ SIGNATURES = {
     "ll_qk_norm_rope_kv_store": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_kv_roll": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_gemm_bf16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
-    "ll_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
-    "ll_gemm_splitk_workspace_bytes": [_i, _i],
-    "ll_gemm_splitk_plan": [_i, _i, _i, _i],
     "ll_gemm_ksplit_plan": [_i, _i, _i],
     "ll_gemm_ksplit_workspace_bytes": [_i, _i, _i],
     "ll_gemm_bf16_ksplit": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _ll, _p],
     "ll_gemm_bf16_ksplit_t5norm": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _p, _ll, _p],
-    "ll_gemm_splitk_status": [_p, _p, _p],
-    "ll_gemm_w8a8_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p],
     "ll_gemm_w8a8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     "ll_gemm_bf16_qkv": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_gemm_w8a8_qkv": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ll_quantize_rows": [_p, _p, _p, _i, _i, _i, _p],
     "ll_linear_small": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p, _ll, _p],
+    "ll_flash_attn": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _i, _i, _f, _p],
     "ll_patchify": [_p, _p, _i, _i, _i, _i, _i, _p],
     "ll_sinusoid": [_p, _p, _i, _i, _p],
     "ll_unpatchify_x0": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "ll_add_noise": [_p, _p, _p, _p, _i, _ll, _p],
     "ll_sigma_lookup": [_p, _p, _p, _p, _i, _i, _p],
     "ll_synth_hash": [_p, _ll, _ll, C.c_ulonglong, _i, _p],
+    "ll_gemm_ssq_planes": [_i, _i, _i],
+    "ll_gemm_bf16_ssq": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ll_flash_attn_qnorm_ok": [_i, _i],
+    "ll_flash_attn_qnorm": [_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _f, _p],
     "ll_conv_cl": [_p] * 6 + [_i] * 10 + [_p],
     "ll_rms_silu_cl": [_p, _p, _p, _ll, _i, _i, _p],
     "ll_softmax_rows": [_p, _p, _i, _i, _i, _f, _p],
@@ -62,8 +60,7 @@ SIGNATURES = {
     "ll_gather_rows": [_p, _p, _p, _i, _i, _ll, _p],
     "ll_t5_attention": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
 }
-_RESTYPES = {"ll_last_error": C.c_char_p, "ll_flash_attn_workspace_bytes": C.c_longlong,
-             "ll_gemm_splitk_workspace_bytes": C.c_longlong, "ll_gemm_ksplit_workspace_bytes": C.c_longlong}
+_RESTYPES = {"ll_last_error": C.c_char_p, "ll_gemm_ksplit_workspace_bytes": C.c_longlong}
 
 _lib = None
 

@@ -6,6 +6,12 @@ __global__ __launch_bounds__(256, 1) void LL_ASM_NAME(const bf16* __restrict__ Q
 #ifdef LL_ASM_DIAG
                                                                 , unsigned long long* dbg
 #endif
+#ifdef LL_ASM_QNORM
+                                                                // Q is the raw projection output; ssq[plane][B * Lq] (fp32) = its per-row sums of squares per
+                                                                // 128-column plane, nw[H * 128] the RMSNorm weight (gen/attn_asm_gen.py: QNORM form)
+                                                                , const float* __restrict__ ssq, int nplanes, long long plane_stride, const bf16* __restrict__ nw,
+                                                                float inv_c, float eps
+#endif
 ) {
   // XCD-aware placement as flash_attn_pipe_kernel: workgroup ids that share an XCD (id % 8) take a contiguous head-major range
   const int b = blockIdx.z;
@@ -35,6 +41,10 @@ __global__ __launch_bounds__(256, 1) void LL_ASM_NAME(const bf16* __restrict__ Q
   unsigned unt = (unsigned)nt, lastv = (unsigned)(nkeys - (nt - 1) * ASM_KT);
   unsigned nrec = (unsigned)(nkeys - 1) * ldk_b + 256u;          // bytes from the head's first key to the end of its last key
   unsigned tid = threadIdx.x;
+#ifdef LL_ASM_QNORM
+  unsigned long long sqb = (unsigned long long)(ssq + (size_t)b * Lq + q0), nwb = (unsigned long long)(nw + head * 128);
+  unsigned sq_stride = (unsigned)(plane_stride * 4), unp = (unsigned)nplanes;
+#endif
   asm volatile(
 #include LL_ASM_INC
       :
@@ -43,7 +53,10 @@ __global__ __launch_bounds__(256, 1) void LL_ASM_NAME(const bf16* __restrict__ Q
 #ifdef LL_ASM_DIAG
         , "{s[56:57]}"(dbg), "{s58}"(lid_ + gridDim.x * b)
 #endif
-      : "memory", "v255", "a255", "s79", "vcc");
+#ifdef LL_ASM_QNORM
+        , "{s[80:81]}"(sqb), "{s82}"(sq_stride), "{s83}"(unp), "{s[84:85]}"(nwb), "{s86}"(inv_c), "{s87}"(eps)
+#endif
+      : "memory", "v255", "a255", "s79", "s95", "vcc");
   __builtin_unreachable();
 }
 

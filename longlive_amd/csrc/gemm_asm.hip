@@ -47,6 +47,16 @@
 #undef GA_WN
 #undef GA_INC
 
+#define GA_NAME gemm_asm_128_bias_ssq
+#define GA_WN 128
+#define GA_INC "build/gemm_asm_128_5.inc"
+#define GA_SSQ 1
+#include "gemm_asm_kernel.inl"
+#undef GA_SSQ
+#undef GA_NAME
+#undef GA_WN
+#undef GA_INC
+
 #define GA_NAME gemm_asm_128_partial
 #define GA_WN 128
 #define GA_INC "build/gemm_asm_128_4.inc"
@@ -144,6 +154,25 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
                   (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm,
                   (void*)&v_out, (void*)&v_col0, (void*)&v_C, (void*)&v_shift, (void*)&v_lo, (void*)&v_hi};
   if (hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s) != hipSuccess) return ll_check_launch("gemm_asm");
+  return 1;
+}
+
+// The bias kernel that also leaves per-row sums of squares of its outputs: ssq[N / 128][M] fp32 (plane = n-tile).  1 = launched,
+// 0 = not covered, < 0 = error.
+int gemm_asm_ssq_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* out, float* ssq, int M, int N, int K, int ldx, int ldo, int gm,
+                        hipStream_t s) {
+  if (gemm_asm_width(M, N, K, ldx, LL_EPI_BIAS, true, false, false, 0) != 128) return 0;
+  const void* fn = (const void*)gemm_asm_128_bias_ssq;
+  const int lds = 3 * 128 * 128 + 4 * 2 * 8192;
+  if (int rc = ll_lds_attr(fn, lds)) return rc;
+  const int ntm = (M + 255) / 256, ntn = N / 128;
+  const bf16* nullb = nullptr;
+  bf16* nov = nullptr;
+  int zero = 0;
+  void* args[] = {(void*)&x, (void*)&w, (void*)&bias, (void*)&out, (void*)&nullb, (void*)&nullb, (void*)&M, (void*)&N, (void*)&K,
+                  (void*)&ldx, (void*)&ldo, (void*)&zero, (void*)&zero, (void*)&ntm, (void*)&ntn, (void*)&gm,
+                  (void*)&nov, (void*)&zero, (void*)&zero, (void*)&zero, (void*)&zero, (void*)&zero, (void*)&ssq};
+  if (hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s) != hipSuccess) return ll_check_launch("gemm_asm_128_bias_ssq");
   return 1;
 }
 

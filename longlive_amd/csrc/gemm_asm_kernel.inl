@@ -9,6 +9,9 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
 #ifdef GA_I8
                                                   , const float* __restrict__ sx, const float* __restrict__ sw
 #endif
+#ifdef GA_SSQ
+                                                  , float* __restrict__ ssq      // [ntn][M]: row sums of squares of this n-tile's outputs
+#endif
                                                   ) {
   int mt, nt;
 #ifdef GA_PARTIAL
@@ -55,6 +58,9 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
     ldo_b = (unsigned)v_C * 2u;
   }
 #endif
+#ifdef GA_SSQ
+  unsigned long long ssqb = (unsigned long long)(ssq + (size_t)nt * M + m0);
+#endif
   asm volatile(
 #include GA_INC
       :
@@ -63,6 +69,9 @@ __global__ __launch_bounds__(256, 1) void GA_NAME(const bf16* __restrict__ X, co
         "{s27}"(gstride), "{s28}"(um0), "{s29}"(row_lo), "{v0}"(tid)
 #ifdef GA_I8
         , "{s[64:65]}"(sxb), "{s[66:67]}"(swb)
+      : "memory", "v255", "a255", "s79", "vcc");
+#elif defined(GA_SSQ)
+        , "{s[64:65]}"(ssqb)
       : "memory", "v255", "a255", "s79", "vcc");
 #else
       : "memory", "v255", "a255", "s63", "vcc");

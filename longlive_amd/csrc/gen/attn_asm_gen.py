@@ -50,6 +50,13 @@ PFX = "LL"                                   # label prefix (one per kernel in t
 DIAG = False                                 # diagnostic build only (tools/attn_asm_diag.hip): s_memtime stamps around the phases of every
                                              # tile, summed per wave and stored to a debug buffer (s[56:57] + 32 * (4 * s58 + wave)); never in the library
 S_DBG, S_WG = 56, 58
+# QNORM form (flash_attn_asm_qn_kernel): Q arrives as the RAW output of the q projection and is RMS-normalised in the prologue
+# (WanRMSNorm over all C = H * 128 channels of the row, wan/modules/model.py:78-86, as cross-attention applies it to q: :172) from the
+# per-(n-tile, row) sums of squares the projection's epilogue left (gemm_asm_128_bias_ssq):
+S_SSQ, S_SSQ_STRIDE, S_NPART, S_NW, S_INVC, S_EPS = 80, 82, 83, 84, 86, 87      # s[80:81] sums at the workgroup's first row (fp32, bytes); bytes between
+                                             # n-tile planes; planes; s[84:85] norm weight at the head's first channel (bf16); 1 / C; eps (fp32 bits)
+S_C2 = 44                                    # (c, c) in s[44:45]: packed-multiply operand
+NPART_MAX = 16                               # planes summed (absent ones read as +0: x + 0 is exact), in plane order
 import os as _os
 
 # ---- schedule / timing knobs (environment ASM_<name>, ASM_G_<name> for the GEMM generator) ---------------------------------
@@ -393,7 +400,7 @@ def ret_dispatch(g: Gen, ret_labels):
 
 
 # ---- the kernel -------------------------------------------------------------------------------------------------------
-def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str:
+def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm: bool = False) -> str:
     global DMA, PFX, DIAG
     assert dma == "buffer"
     DMA, PFX, DIAG = dma, prefix, diag
@@ -490,10 +497,14 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     I(f"s_sub_u32 {sreg(S_T1)}, {sreg(S_ROWS)}, 1")
     for qb in range(2):
         I(f"v_min_u32 {vreg(V_T + qb)}, {sreg(S_T1)}, {vreg(V_ROW + qb)}")
+        if qnorm:
+            I(f"v_lshlrev_b32 {vreg(V_T + 2 + qb)}, 2, {vreg(V_T + qb)}")                # byte offset of the (clamped) row's sum inside a plane
         I(f"v_mul_lo_u32 {vreg(V_T + qb)}, {vreg(V_T + qb)}, {sreg(S_LDQ)}")
         I(f"v_lshl_add_u32 {vreg(V_T + qb)}, {vreg(V_H)}, 4, {vreg(V_T + qb)}")      # + 8 h elements = 16 h bytes
         for ks in range(8):
             I(f"global_load_dwordx4 {vreg(64 * 0 + 32 * qb + 4 * ks, 4)}, {vreg(V_T + qb)}, {sreg(S_Q, 2)} offset:{32 * ks}")
+    if qnorm:
+        gen_qnorm_loads(g)
     # O = 0, l = 0 while the loads fly
     for r in range(128):
         I(f"v_accvgpr_write_b32 {areg(A_O + r)}, 0")
@@ -503,7 +514,9 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
         for k in range(4):
             I(f"v_mov_b32 {vreg(V_ONES + k)}, 0x3f803f80")
     I("s_waitcnt vmcnt(0)")                           # Q, and every staged tile of the prologue
-    for qb in range(2):
+    if qnorm:
+        gen_qnorm_convert(g)
+    for qb in range(0 if qnorm else 2):
         for ks in range(8):
             for j in range(4):
                 src = 32 * qb + 4 * ks + j
@@ -613,6 +626,70 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False) -> str
     I("s_waitcnt vmcnt(0)")
     I("s_endpgm")
     return finalize(g.out).replace("LL_", PFX + "_")
+
+
+# ---- QNORM prologue ------------------------------------------------------------------------------------------------------
+QN_W, QN_SS, QN_RI = 64, 96, 128             # v[64:95] norm weight (packed bf16, the lane's 8 channels of each k-step), v[96:127] the planes' sums
+                                             # per q-block (16 each), v[128:131] (rinv, rinv) per q-block -- all inside the score buffers / -m tiles,
+                                             # which are first written by tile 0
+
+
+def gen_qnorm_loads(g: Gen):
+    """after the Q loads: the head's norm weight (the lane's channels 16 ks + 8 h + (0..7)) and the row's sums of squares, one per
+    n-tile plane of the projection (planes past S_NPART are not read: their registers stay +0)"""
+    I = g.I
+    I(f"v_lshlrev_b32 {vreg(V_T + 4)}, 4, {vreg(V_H)}")                       # 16 h bytes
+    for ks in range(8):
+        I(f"global_load_dwordx4 {vreg(QN_W + 4 * ks, 4)}, {vreg(V_T + 4)}, {sreg(S_NW, 2)} offset:{32 * ks}")
+    for k in range(2 * NPART_MAX):
+        I(f"v_mov_b32 {vreg(QN_SS + k)}, 0")
+    I(f"s_mov_b64 {sreg(S_T2, 2)}, {sreg(S_SSQ, 2)}")                          # running plane base (s[38:39])
+    for j in range(NPART_MAX):
+        I(f"s_cmp_ge_u32 {j}, {sreg(S_NPART)}")
+        I(f"s_cbranch_scc1 {PFX}_QN_LOADED")
+        for qb in range(2):
+            I(f"global_load_dword {vreg(QN_SS + 16 * qb + j)}, {vreg(V_T + 2 + qb)}, {sreg(S_T2, 2)}")
+        I(f"s_add_u32 {sreg(S_T2)}, {sreg(S_T2)}, {sreg(S_SSQ_STRIDE)}")
+        I(f"s_addc_u32 {sreg(S_T3)}, {sreg(S_T3)}, 0")
+    g.L(f"{PFX}_QN_LOADED")
+
+
+def gen_qnorm_convert(g: Gen):
+    """q <- bf16( bf16( bf16(x * rinv) * w ) * c ) with rinv = rsq(sum / C + eps): WanRMSNorm's rounding points (x.float() * rsqrt(...)
+    rounded to bf16, times the bf16 weight, rounded) followed by this kernel's pre-scaling by c = scale * log2(e)."""
+    I = g.I
+    for qb in range(2):
+        b = QN_SS + 16 * qb
+        for j in range(1, NPART_MAX):                                          # plane order, fixed
+            I(f"v_add_f32 {vreg(b)}, {vreg(b)}, {vreg(b + j)}")
+        I(f"v_mov_b32 {vreg(QN_RI + 2 * qb + 1)}, {sreg(S_EPS)}")
+        I(f"v_fma_f32 {vreg(b)}, {vreg(b)}, {sreg(S_INVC)}, {vreg(QN_RI + 2 * qb + 1)}")
+        I(f"v_rsq_f32 {vreg(QN_RI + 2 * qb)}, {vreg(b)}")
+        I("s_nop 0")
+        I(f"v_mov_b32 {vreg(QN_RI + 2 * qb + 1)}, {vreg(QN_RI + 2 * qb)}")
+    I(f"s_mov_b32 {sreg(S_C2)}, {sreg(S_C)}")
+    I(f"s_mov_b32 {sreg(S_C2 + 1)}, {sreg(S_C)}")
+    for qb in range(2):
+        for ks in range(8):
+            for j in range(4):
+                src, wsrc = 32 * qb + 4 * ks + j, QN_W + 4 * ks + j
+                t = V_T + 4 + 4 * (j & 1)                                      # two temporaries sets, alternating
+                lo, hi, wl, wh = t, t + 1, t + 2, t + 3
+                I(f"v_lshlrev_b32 {vreg(lo)}, 16, {vreg(src)}")
+                I(f"v_and_b32 {vreg(hi)}, 0xffff0000, {vreg(src)}")
+                I(f"v_pk_mul_f32 {vreg(lo, 2)}, {vreg(lo, 2)}, {vreg(QN_RI + 2 * qb, 2)}")
+                I(f"v_cvt_pk_bf16_f32 {vreg(lo)}, {vreg(lo)}, {vreg(hi)}")
+                I(f"v_and_b32 {vreg(hi)}, 0xffff0000, {vreg(lo)}")
+                I(f"v_lshlrev_b32 {vreg(lo)}, 16, {vreg(lo)}")
+                I(f"v_lshlrev_b32 {vreg(wl)}, 16, {vreg(wsrc)}")
+                I(f"v_and_b32 {vreg(wh)}, 0xffff0000, {vreg(wsrc)}")
+                I(f"v_pk_mul_f32 {vreg(lo, 2)}, {vreg(lo, 2)}, {vreg(wl, 2)}")
+                I(f"v_cvt_pk_bf16_f32 {vreg(lo)}, {vreg(lo)}, {vreg(hi)}")
+                I(f"v_and_b32 {vreg(hi)}, 0xffff0000, {vreg(lo)}")
+                I(f"v_lshlrev_b32 {vreg(lo)}, 16, {vreg(lo)}")
+                I(f"v_pk_mul_f32 {vreg(lo, 2)}, {sreg(S_C2, 2)}, {vreg(lo, 2)}")
+                I(f"v_cvt_pk_bf16_f32 {vreg(lo)}, {vreg(lo)}, {vreg(hi)}")
+                I(f"v_accvgpr_write_b32 {areg(A_Q + 32 * qb + 4 * ks + j)}, {vreg(lo)}")
 
 
 def rescale_rets(x):
@@ -905,7 +982,10 @@ if __name__ == "__main__":
         k = sys.argv.index("--dma")
         mode = sys.argv[k + 1]
         del sys.argv[k:k + 2]
-    txt = generate(mode, "LL" + mode[0].upper() + ("D" if diag else ""), diag)
+    qnorm = "--qnorm" in sys.argv
+    if qnorm:
+        sys.argv.remove("--qnorm")
+    txt = generate(mode, "LL" + mode[0].upper() + ("D" if diag else "") + ("N" if qnorm else ""), diag, qnorm)
     probs = lint(txt)
     for p in probs[:40]:
         print("LINT:", p, file=sys.stderr)

@@ -37,6 +37,9 @@ from attn_asm_gen import Gen, finalize, lint, sreg, vreg, areg, to_inc, f32bits,
 
 EPI_BIAS, EPI_GELU, EPI_GATE_RES, EPI_RES = 0, 1, 2, 3
 EPI_PARTIAL = 4                                                   # no epilogue: the raw fp32 accumulators (one K-range of a split-K call), Y = float [rows, ldo / 4]
+EPI_BIAS_SSQ = 5                                                  # EPI_BIAS + per-row sum of squares of the tile's bf16 outputs -> ssq[row] (fp32): the statistics of
+                                                                  # the RMSNorm that follows the projection (WanRMSNorm, wan/modules/model.py:78-86 after :172), summed
+                                                                  # over the n-tiles and applied by the consumer (flash_attn_asm_qn_kernel's Q prologue)
 
 # ---- inputs (pinned by the HIP wrapper) ----------------------------------------------------------------------------
 S_X, S_W, S_Y, S_BIAS, S_RES, S_GATE = 8, 10, 12, 14, 16, 18      # 64-bit bases (bytes): X row m0; W row n0; Y / RES at (m0, n0); bias + n0;
@@ -46,6 +49,7 @@ S_ROWS, S_COLS, S_NK = 23, 24, 25                                 # valid rows (
 S_FLEN, S_GSTRIDE, S_M0 = 26, 27, 28                              # gate: frame_len (rows per frame), bytes between frames' gate rows, m0
 S_ROWLO = 29                                                      # first row of the tile that is stored (0 except in V tiles of the fused QKV projection)
 S_SX, S_SW = 64, 66                                               # W8A8 kernels: 64-bit bases of the activation scales (sx + m0) and weight scales (sw + n0), fp32
+S_SSQ = 64                                                        # EPI_BIAS_SSQ (bf16 only): 64-bit base of this tile's row sums, fp32 [rows] (ssq + n_tile * M + m0)
 # working scalars
 S_XRS, S_WRS = 32, 36                                             # descriptors
 S_WAVE, S_I, S_T0, S_T1, S_T2 = 40, 41, 44, 45, 46
@@ -66,7 +70,7 @@ def KN(k):
 class Cfg:
     def __init__(self, WN, epi, i8=False):
         assert WN % 32 == 0 and 64 <= WN <= 256
-        assert not (i8 and epi == EPI_PARTIAL)
+        assert not (i8 and epi in (EPI_PARTIAL, EPI_BIAS_SSQ))
         self.WN, self.NB, self.MB, self.epi, self.i8 = WN, WN // 32, 2, epi, i8
         self.nacc = self.MB * self.NB * 16
         self.slotb = WN * 128                                      # bytes of one W slot: WN rows x 128 B (a 64-deep K-step)
@@ -98,6 +102,8 @@ class Cfg:
         self.nl = {EPI_GATE_RES: 6, EPI_RES: 2}.get(epi, 0)       # global reads per epilogue block
         self.V_E0 = top                                           # the first block's gate / residual pieces (16 registers) when nl
         top += 16 if self.nl else 0
+        self.V_SS = top                                           # EPI_BIAS_SSQ: running sums of squares SS[mb] = 2 registers each (even / odd column of a pair)
+        top += 4 if epi == EPI_BIAS_SSQ else 0
         self.V_EB = top                                           # early bias [nb][g4], 2 registers each
         self.early_nb = 0 if epi == EPI_PARTIAL else max(0, min(self.NB, (256 - top) // 8))
 
@@ -407,6 +413,9 @@ def gen_epilogue(g: Gen, c: Cfg):
         cons[name] = s0
     if epi == EPI_GELU:
         const_pair("k1", K1, 54); const_pair("k0", K0, 56); const_pair("ce", CEXP, 58); const_pair("one", 1.0, 60)
+    if epi == EPI_BIAS_SSQ:
+        for k in range(2 * c.MB):
+            I(f"v_mov_b32 {vreg(c.V_SS + k)}, 0")
     if epi == EPI_PARTIAL:
         # fp32 accumulators as they stand: a lane owns row m, columns 32 nb + 8 g4 + 4 h + (0..3) = 16 contiguous bytes per group
         for nb in range(c.NB):
@@ -490,10 +499,13 @@ def gen_epilogue(g: Gen, c: Cfg):
             I(f"v_pk_add_f32 {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(T + 24 + r, 2)}")
         for r in range(0, 16, 2):                                            # round to bf16 and back
             I(f"v_cvt_pk_bf16_f32 {vreg(T + 16 + r // 2)}, {vreg(T + r)}, {vreg(T + r + 1)}")
-        if epi in (EPI_GELU, EPI_GATE_RES):
+        if epi in (EPI_GELU, EPI_GATE_RES, EPI_BIAS_SSQ):
             for r in range(0, 16, 2):
                 I(f"v_lshlrev_b32 {vreg(T + r)}, 16, {vreg(T + 16 + r // 2)}")
                 I(f"v_and_b32 {vreg(T + r + 1)}, 0xffff0000, {vreg(T + 16 + r // 2)}")
+        if epi == EPI_BIAS_SSQ:                                              # SS[mb] += v * v of the ROUNDED outputs, fixed order: nb, then the 8 pairs
+            for r in range(0, 16, 2):
+                I(f"v_pk_fma_f32 {vreg(c.V_SS + 2 * mb, 2)}, {vreg(T + r, 2)}, {vreg(T + r, 2)}, {vreg(c.V_SS + 2 * mb, 2)}")
         if epi == EPI_GATE_RES:                                              # w = bf16(v * gate[frame][n])
             for r in range(0, 16, 2):
                 src = P + r // 2
@@ -545,6 +557,27 @@ def gen_epilogue(g: Gen, c: Cfg):
             I(f"global_store_dwordx4 {vreg(EA + mb)}, {vreg(T + 16 + 2 * k, 4)}, {sreg(S_Y, 2)} offset:{off_y + 16 * k}")
         I("s_mov_b64 exec, -1")
         q.extend([("st", j)] * 2)
+    if epi == EPI_BIAS_SSQ:
+        # row sum of the tile: (even + odd columns) of this half, + the other half of the wave (lanes r and r + 32 hold the two
+        # halves of row r's columns); one 4-byte store per valid row from the lower half
+        for mb in range(c.MB):
+            ss = c.V_SS + 2 * mb
+            I(f"v_add_f32 {vreg(ss)}, {vreg(ss)}, {vreg(ss + 1)}")
+            I(f"v_mov_b32 {vreg(ss + 1)}, {vreg(ss)}")
+        I("s_nop 1")
+        for mb in range(c.MB):
+            ss = c.V_SS + 2 * mb
+            I(f"v_permlane32_swap_b32 {vreg(ss)}, {vreg(ss + 1)}")          # ss = (lower, lower), ss + 1 = (upper, upper)
+        for mb in range(c.MB):
+            ss = c.V_SS + 2 * mb
+            I(f"v_add_f32 {vreg(ss)}, {vreg(ss)}, {vreg(ss + 1)}")
+            I(f"v_lshlrev_b32 {vreg(T + mb)}, 2, {vreg(c.V_ROW + mb)}")                 # byte offset of the row's sum
+            I(f"v_cmp_eq_u32_e64 vcc, {vreg(c.V_H)}, 0")
+            I(f"s_and_b64 vcc, vcc, {sreg(S_MSK + 2 * mb, 2)}")
+            I("s_mov_b64 exec, vcc")
+            I(f"global_store_dword {vreg(T + mb)}, {vreg(ss)}, {sreg(S_SSQ, 2)}")
+            I("s_mov_b64 exec, -1")
+            q.append(("st", "ssq"))
     n = 0
     while n < len(q) and q[len(q) - 1 - n][0] == "st":
         n += 1

@@ -136,7 +136,8 @@ class CausalWanModelHIP(nn.Module):
         self.quant: Optional[str] = None
         self.use_modulation_table = True      # modulation + e0 once per (layer, frame) instead of once per token row (A/B switch)
         self.fuse_v_insert = True             # the QKV projection's epilogue writes V into the KV cache (A/B switch)
-        self.ffn2_splitk = True               # FFN2 as 256x256 tiles x split-K 2 (ll_gemm_bf16_splitk / ll_gemm_w8a8_splitk; A/B switch)
+        self.fuse_cross_qnorm = True          # cross-attention q: RMSNorm statistics from the projection's epilogue, applied in the attention
+                                              # kernel's Q prologue (no RMSNorm launch) where both generated kernels cover the call (A/B switch)
         self._packed = None
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -222,7 +223,6 @@ class CausalWanModelHIP(nn.Module):
         """One block linear: bf16 MFMA GEMM, or W8A8 GEMM in int8 mode (same fused epilogues).  In int8 mode `x` is either
         a bf16 tensor (quantised here, per token) or an already quantised (int8, scale) pair from a fused producer."""
         if self.quant == "int8":
-            kw.pop("splitk", None)      # W8A8 FFN2: the split-K form measured 76.6 -> 88 us (half the K-steps, same exchange): not used
             xq, sx = x if isinstance(x, tuple) else ops.quantize_rows(x)
             return ops.gemm_w8a8(xq, sx, pk["q_" + key], pk["s_" + key], b, epilogue, tag="gemm_" + key, **kw)
         return ops.gemm(x, w, b, epilogue, tag="gemm_" + key, **kw)
@@ -344,7 +344,11 @@ class CausalWanModelHIP(nn.Module):
                   mod=mod, gate_idx=2, rows_per_batch=L, frame_len=fs)
         # --- cross attention (causal_model.py:460; model.py:159-194) ---
         xn = (ops.layernorm_affine_q8 if q8 else ops.layernorm_affine)(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
-        qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
+        fuse_qn = (self.fuse_cross_qnorm and not q8 and ops.gemm_ssq_planes(B * L, C, C) == Hh and ops.flash_attn_qnorm_ok(Hh, c.text_len))
+        if fuse_qn:
+            qraw, ssq = ops.gemm_ssq(xn, ca.q.weight, ca.q.bias, tag="gemm_cq")
+        else:
+            qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
         if not cac["is_init"]:
             kc = ops.gemm(ctx, ca.k.weight, ca.k.bias)
             if cac["k"].shape != (B, c.text_len, Hh, D) or not cac["k"].is_contiguous():
@@ -353,15 +357,16 @@ class CausalWanModelHIP(nn.Module):
             ops.rmsnorm(kc, ca.norm_k.weight, c.eps, out=cac["k"].view(B, c.text_len, C))
             ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
             cac["is_init"] = True
-        atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
+        if fuse_qn:
+            atc = ops.flash_attn_qnorm(qraw.view(B, L, Hh, D), ssq, ca.norm_q.weight, c.eps, cac["k"], cac["v"], c.text_len, tag="flash_attn_cross")
+        else:
+            atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
         self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
         # --- FFN (causal_model.py:462-468) ---
         h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 3, 4, F, c.eps)
         ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
         self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
-                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs,
-                  splitk=self.ffn2_splitk and mod is None)      # a per-batch modulation vector is not covered by the generated kernel: such a
-                                                                # call would reach the split-K hand-off kernel, whose status only blocking callers poll
+                  mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs)
         return plan
 
     # ---- forward -----------------------------------------------------------------------------------------------

@@ -224,9 +224,8 @@ def kv_roll(cache_k, cache_v, dst: int, src: int, n: int):
 
 
 def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
-         rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm", splitk: bool = False):
-    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias).  x may be any [..., K] contiguous tensor.  splitk: the split-K kernel for
-    long-K / narrow-N shapes (ll_gemm_bf16_splitk; shapes it does not cover run the ordinary kernels)."""
+         rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm"):
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias).  x may be any [..., K] contiguous tensor."""
     _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias")
     K = x.shape[-1]
     M = x.numel() // K
@@ -249,7 +248,7 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
             assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
-    if not splitk and M <= 1024 and M * N <= (1 << 22) and epilogue in (EPI_BIAS, EPI_BIAS_RES) and _ksplit_plan(lib, M, N, K):
+    if M <= 1024 and M * N <= (1 << 22) and epilogue in (EPI_BIAS, EPI_BIAS_RES) and _ksplit_plan(lib, M, N, K):
         # few rows (the text side: umT5 at 512 tokens, text K / V projections): K cut into ranges so that the grid fills the device.
         # Taken by itself only up to 1024 rows: the DiT's own linears (a 1-frame chunk has M = 1560) never come here, so the order
         # of a row's fp32 sum there does not depend on M or on the device's CU count.  Inside this region the number of ranges
@@ -257,11 +256,6 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
         ws = ksplit_workspace(x.device, M, N, K)
         _lib.check(lib.ll_gemm_bf16_ksplit(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                            _ptr(res), ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_bf16_ksplit")
-    elif splitk:
-        ws = splitk_workspace(x.device, M, N)
-        _lib.check(lib.ll_gemm_bf16_splitk(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
-                                           _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len,
-                                           ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_bf16_splitk")
     else:
         _lib.check(lib.ll_gemm_bf16(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), M, N, K, K, N, epilogue,
                                     _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx, rows_per_batch, frame_len, _stream()),
@@ -270,7 +264,36 @@ def gemm(x, w, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=N
     return out
 
 
-_splitk_ws = {}
+def gemm_ssq_planes(M: int, N: int, K: int) -> int:
+    """128-column planes ll_gemm_bf16_ssq would write for this shape under the current tuning (0 = not covered)."""
+    return int(_lib.load().ll_gemm_ssq_planes(M, N, K))
+
+
+def gemm_ssq(x, w, bias, out=None, tag: str = "gemm"):
+    """(x @ w^T + bias [.., N] bf16, ssq [N / 128, M] fp32): the bias GEMM whose epilogue also leaves, per row and 128-column n-tile,
+    the sum of squares of its bf16 outputs -- the statistics of the RMSNorm that follows a q projection (model.py:172), consumed by
+    flash_attn_qnorm.  Only for shapes gemm_ssq_planes() accepts."""
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    assert w.shape == (N, K) and bias.numel() == N
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=bf16, device=x.device)
+    _chk(out, "out")
+    assert out.numel() == M * N
+    planes = gemm_ssq_planes(M, N, K)
+    if planes == 0:
+        raise RuntimeError(f"gemm_ssq: {M} x {N} x {K} is not covered by the generated kernel (use gemm + rmsnorm)")
+    ssq = torch.empty(planes, M, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    t0 = _t0(tag)
+    _lib.check(lib.ll_gemm_bf16_ssq(x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), ssq.data_ptr(), M, N, K, K, N, _stream()),
+               "ll_gemm_bf16_ssq")
+    _t1(tag, t0, 2.0 * M * N * K)
+    return out, ssq
+
+
 _ksplit_ws = {}
 
 
@@ -293,39 +316,6 @@ def ksplit_workspace(device, M: int, N: int, K: int) -> torch.Tensor:
         buf = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
         _ksplit_ws[key] = buf
     return buf
-
-
-def splitk_workspace(device, M: int, N: int) -> torch.Tensor:
-    """Zeroed scratch for ll_gemm_bf16_splitk, one buffer per (device, STREAM): the kernel's hand-off flags and partial tiles belong
-    to the launches of one stream at a time (two streams may run the same projection concurrently: overlap_context)."""
-    lib = _lib.load()
-    need = int(lib.ll_gemm_splitk_workspace_bytes(M, N))
-    st = torch.cuda.current_stream(device)
-    key = (device.type, _dev_index(device), int(st.cuda_stream or 0))
-    ent = _splitk_ws.get(key)
-    if ent is None or ent[0].numel() < need:
-        ent = (torch.zeros(max(need, 16), dtype=torch.uint8, device=device), st)      # the Stream object is kept: its handle stays valid
-        _splitk_ws[key] = ent
-    return ent[0]
-
-
-def splitk_check() -> None:
-    """BLOCKING: reads back the error word of every split-K workspace (ll_gemm_splitk_status) and raises if a hand-off of any
-    launch since the last check timed out (that launch's output is invalid).  Called where the host synchronises anyway: the end
-    of a pipeline's inference(), bench.py after its timed region, the tests."""
-    if not _splitk_ws:
-        return
-    import ctypes as C
-    lib = _lib.load()
-    bad = []
-    for key, (buf, stream) in list(_splitk_ws.items()):
-        st = C.c_uint(0)
-        with torch.cuda.device(buf.device):
-            _lib.check(lib.ll_gemm_splitk_status(buf.data_ptr(), C.addressof(st), stream.cuda_stream or None), "ll_gemm_splitk_status")
-        if st.value:                          # (flags carry per-launch epochs: stale words never match, nothing needs clearing)
-            bad.append((key, st.value))
-    if bad:
-        raise RuntimeError(f"split-K GEMM hand-off timed out (workspace, launch epoch): {bad}; the outputs of those launches are invalid")
 
 
 def gemm_qkv_v_insert(x, w, bias, cache_v, write_start: int, roped_offset: int, write_len: int, xq=None, tag: str = "gemm_qkv"):
@@ -386,7 +376,7 @@ def quantize_rows(x, q=None, scale=None):
 
 
 def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None, e=None, mod=None, gate_idx: int = 0,
-              rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm", splitk: bool = False):
+              rows_per_batch: int = 0, frame_len: int = 0, tag: str = "gemm"):
     """out[M,N] = epilogue(sx[m] sw[n] (xq[M,K] @ wq[N,K]^T) + bias): int8 operands, int32 accumulation, bf16 out."""
     _chk(xq, "xq", torch.int8); _chk(wq, "wq", torch.int8); _chk(sx, "sx", torch.float32); _chk(sw, "sw", torch.float32)
     _chk(bias, "bias")
@@ -411,15 +401,9 @@ def gemm_w8a8(xq, sx, wq, sw, bias, epilogue: int = EPI_BIAS, out=None, res=None
             assert mod.numel() == nmod * N
     lib = _lib.load()
     t0 = _t0(tag)
-    if splitk:
-        ws = splitk_workspace(xq.device, M, N)
-        _lib.check(lib.ll_gemm_w8a8_splitk(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
-                                           out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
-                                           rows_per_batch, frame_len, ws.data_ptr(), ws.numel(), _stream()), "ll_gemm_w8a8_splitk")
-    else:
-        _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
-                                    out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
-                                    rows_per_batch, frame_len, _stream()), "ll_gemm_w8a8")
+    _lib.check(lib.ll_gemm_w8a8(xq.data_ptr(), sx.data_ptr(), wq.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+                                out.data_ptr(), M, N, K, N, epilogue, _ptr(res), _ptr(e), _ptr(mod), nmod, gate_idx,
+                                rows_per_batch, frame_len, _stream()), "ll_gemm_w8a8")
     _t1(tag, t0, 2.0 * M * N * K)
     return out
 
@@ -441,25 +425,6 @@ def linear_small(x, w, bias, act_in: int = 0, act_out: int = 0):
     return out
 
 
-_attn_ws = {}
-
-
-def attn_workspace(device) -> Optional[torch.Tensor]:
-    """Scratch for ll_flash_attn's stream-K path (the ABI never allocates).  None while stream-K is off (the default tuning:
-    ll_flash_attn_workspace_bytes() == 0), otherwise one buffer per (device, STREAM) -- two streams may run self-attention
-    concurrently (overlap_context) and a launch reads back what it wrote itself."""
-    lib = _lib.load()
-    need = int(lib.ll_flash_attn_workspace_bytes())
-    if need == 0:
-        return None
-    key = (device.type, _dev_index(device), int(_stream() or 0))
-    buf = _attn_ws.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(need, dtype=torch.uint8, device=device)
-        _attn_ws[key] = buf
-    return buf
-
-
 def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None, tag: Optional[str] = None):
     """q [B,Lq,H,128] (contiguous); k,v [B,Sk,H,128]; keys = concatenation of up to two row ranges
     [(start, end), ...] of k/v.  Returns [B,Lq,H,128]."""
@@ -479,18 +444,41 @@ def flash_attn(q, k, v, segments, out=None, scale: Optional[float] = None, tag: 
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     lib = _lib.load()
-    ws = attn_workspace(q.device)
     t0 = None
     if timer is not None:
         nkeys = (e0 - s0) + (e1 - s1)
         tag = tag or "flash_attn"
         t0 = timer.begin(tag)
     _lib.check(lib.ll_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, Lq, H, H * D, H * D,
-                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, _ptr(ws), 0 if ws is None else ws.numel(),
-                                 _stream()),
+                                 H * D, Sk * H * D, s0, e0 - s0, s1, e1 - s1, scale, _stream()),
                "ll_flash_attn")
     if timer is not None:
         timer.end(tag, t0, 4.0 * B * H * Lq * nkeys * D)     # algorithmic FLOPs: QK^T + PV
+    return out
+
+
+def flash_attn_qnorm_ok(H: int, nkeys: int) -> bool:
+    return bool(_lib.load().ll_flash_attn_qnorm_ok(H, nkeys))
+
+
+def flash_attn_qnorm(q, ssq, norm_w, eps: float, k, v, nkeys: int, out=None, scale: Optional[float] = None, tag: Optional[str] = None):
+    """Attention over keys [0, nkeys) of k / v with WanRMSNorm(q; norm_w) applied inside the kernel: q [B,Lq,H,128] is the RAW
+    projection output and ssq [H, B*Lq] its per-plane row sums of squares (gemm_ssq).  model.py:172,189 in two launches."""
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v"); _chk(norm_w, "norm_w"); _chk(ssq, "ssq", torch.float32)
+    B, Lq, H, D = q.shape
+    assert D == 128 and norm_w.numel() == H * D and ssq.shape == (H, B * Lq), (q.shape, ssq.shape, norm_w.shape)
+    Sk = k.shape[1]
+    assert k.shape == (B, Sk, H, D) and v.shape == k.shape and 0 < nkeys <= Sk
+    out = torch.empty_like(q) if out is None else _chk(out, "out")
+    assert out.shape == q.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    lib = _lib.load()
+    tag = tag or "flash_attn"
+    t0 = _t0(tag)
+    _lib.check(lib.ll_flash_attn_qnorm(q.data_ptr(), ssq.data_ptr(), norm_w.data_ptr(), eps, k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                       B, Lq, H, H * D, H * D, H * D, Sk * H * D, 0, nkeys, scale, _stream()), "ll_flash_attn_qnorm")
+    _t1(tag, t0, 4.0 * B * H * Lq * nkeys * D)
     return out
 
 

@@ -13,7 +13,6 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops as _ops
 from ..wan_wrapper import WanDiffusionWrapper
 
 
@@ -171,7 +170,6 @@ class CausalInferencePipeline(nn.Module):
             self._clean_context_pass(denoised, cond, start)
             yield start, denoised
         self._join_context()
-        _ops.splitk_check()           # end of the stream (blocking): a split-K hand-off that timed out anywhere in it raises here
 
     @torch.no_grad()
     def stream_video(self, noise: torch.Tensor, text_prompts, output: Optional[torch.Tensor] = None,
@@ -260,7 +258,6 @@ class CausalInferencePipeline(nn.Module):
             video = self.vae.decode_to_pixel(output, use_cache=False)
             video = (video * 0.5 + 0.5).clamp(0, 1)
         prof.stop("vae")
-        _ops.splitk_check()           # the natural sync of a run: raises if a split-K hand-off timed out (invalid output)
         self.last_profile = prof.report(self.num_frame_per_block, switch_blocks=())
         if return_latents:
             return video, output

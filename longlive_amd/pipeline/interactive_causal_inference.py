@@ -6,7 +6,6 @@ from typing import List
 
 import torch
 
-from .. import ops as _ops
 from .causal_inference import CausalInferencePipeline, _Profiler
 
 
@@ -94,7 +93,6 @@ class InteractiveCausalInferencePipeline(CausalInferencePipeline):
             video = self.vae.decode_to_pixel(output, use_cache=False)
             video = (video * 0.5 + 0.5).clamp(0, 1)
         prof.stop("vae")
-        _ops.splitk_check()           # the natural sync of a run: raises if a split-K hand-off timed out (invalid output)
         self.last_profile = prof.report(self.num_frame_per_block, switch_blocks=tuple(switch_blocks))
         if return_latents:
             return video, output

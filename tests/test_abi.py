@@ -54,17 +54,17 @@ def test_no_torch_types_in_the_abi():
     (lambda L: L.ll_kv_roll(0, 0, 1, 100, 1536, 5, 90, 20, None), "outside cache"),
     (lambda L: L.ll_qk_norm_rope_kv_store(0, 0, 0, 0, 0, 0, 0, 0, 1, 4680, 1536, 128, 1560, 1023, 18720, 0, 0, 4680, 1e-6, None), "RoPE table"),
     (lambda L: L.ll_qk_norm_rope_kv_store(0, 0, 0, 0, 0, 0, 0, 0, 1, 4680, 1536, 128, 1560, 0, 18720, 18000, 0, 4680, 1e-6, None), "outside cache"),
-    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 0, 0, 0, 0.088, None, 0, None), "non-empty"),
-    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 64, 0, 0, 0.088, None, 4096, None), "workspace"),
+    (lambda L: L.ll_flash_attn(0, 0, 0, 0, 1, 128, 12, 1536, 1536, 1536, 0, 0, 0, 0, 0, 0.088, None), "non-empty"),
+    (lambda L: L.ll_flash_attn_qnorm(1, 1, 1, 1e-6, 1, 1, 1, 1, 128, 12, 1536, 1536, 1536, 0, 0, 16, 0.088, None), "not covered"),
+    (lambda L: L.ll_flash_attn_qnorm(1, 1, 1, 1e-6, 1, 1, 1, 1, 128, 12, 3072, 1536, 1536, 0, 0, 512, 0.088, None), "whole projection output"),
+    (lambda L: L.ll_gemm_bf16_ssq(1, 1, 1, 1, 4, 300, 136, 256, 256, 136, None), "not covered"),
+    (lambda L: L.ll_synth_hash(None, 0, 10, 1, 2, None), "kind"),
     (lambda L: L.ll_linear_small(0, 0, 0, 0, 9, 64, 64, 0, 0, None), "M=9"),
     (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 0, 1, 128, 64, 0, 0, 128, None), "cache_v"),
     (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 1, 1, 100, 64, 0, 0, 10, None), "not B"),
     (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 1, 1, 128, 64, 60, 0, 10, None), "outside cache"),
     (lambda L: L.ll_gemm_bf16(0, 0, 1, 0, 128, 128, 128, 128, 128, 2, 0, 0, 0, 6, 2, 128, 64, None), "res and e"),
     (lambda L: L.ll_modulation_table(0, 0, 0, 30, 3, 6, 1537, None), "bad shape"),
-    (lambda L: L.ll_gemm_bf16_splitk(0, 0, 1, 0, 4680, 1536, 8960, 8000, 1536, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "ldx=8000"),
-    (lambda L: L.ll_gemm_bf16_splitk(0, 0, 1, 0, 4680, 1536, 8960, 8960, 1536, 3, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "needs res"),
-    (lambda L: L.ll_gemm_w8a8_splitk(0, 0, 0, 0, 1, 0, 4680, 1536, 8960, 1536, 0, 0, 0, 0, 0, 0, 0, 0, None, 0, None), "scales"),
     (lambda L: L.ll_conv_cl(0, 1, 1, 1, 0, 1, 2, 16, 32, 96, 96, 2624, 3, 3, 0, 96, None), "null operand"),
     (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 1, 0, None, 0, None), "bias or bias + residual"),
     (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 3, 0, None, 0, None), "needs res"),
@@ -82,15 +82,11 @@ def test_invalid_arguments_are_rejected_before_launch(call, needle):
         _lib.check(rc, "test")
 
 
-def test_splitk_workspace_size_and_plan_without_a_gpu():
-    """Host-only helpers of the split-K GEMM: flags page + 2 x 128 KiB of fp32 half-tiles per 256 x 256 tile; a shape is only
-    planned as split-K on a device whose CUs hold the whole grid (none here)."""
+def test_small_m_split_k_plan_without_a_gpu():
+    """Host-only helper of the small-M split-K path: not planned without a device (the CU count decides)."""
     lib = _lib.load()
-    assert lib.ll_gemm_splitk_workspace_bytes(4680, 1536) == 4096 + 19 * 6 * 2 * 8 * 16 * 64 * 4 * 4
-    assert lib.ll_gemm_splitk_workspace_bytes(4680, 1500) == 0 and lib.ll_gemm_splitk_workspace_bytes(0, 1536) == 0
     import torch
     if not torch.cuda.is_available():
-        assert lib.ll_gemm_splitk_plan(4680, 1536, 8960, 0) == 0
         assert lib.ll_gemm_ksplit_plan(512, 4096, 4096) == 0 and lib.ll_gemm_ksplit_workspace_bytes(512, 4096, 4096) == 0
 
 
@@ -102,8 +98,8 @@ def test_gemm_plan_names_the_kernel_family_a_call_takes():
     lib = _lib.load()
     buf = C.create_string_buffer(256)
 
-    def plan(M, N, K, i8, epi, plain, sk=0):
-        _lib.check(lib.ll_gemm_plan_epi(M, N, K, i8, epi, plain, sk, buf, 256), "plan")
+    def plan(M, N, K, i8, epi, plain):
+        _lib.check(lib.ll_gemm_plan_epi(M, N, K, i8, epi, plain, buf, 256), "plan")
         return buf.value.decode()
 
     L, Cw, F1 = 4680, 1536, 8960
@@ -115,15 +111,16 @@ def test_gemm_plan_names_the_kernel_family_a_call_takes():
     assert "760 workgroups" in plan(L, F1, Cw, 0, 1, 1) and "456 workgroups" in plan(L, 3 * Cw, Cw, 0, 0, 2)
     for text in (plan(L, Cw, Cw, 1, 2, 1), plan(L, Cw, Cw, 0, 2, 0), plan(L, 1000, Cw, 0, 0, 1), plan(L, F1, 192, 0, 1, 1)):
         assert text.startswith("gemm_kernel_v"), text                                # int8; modulation vector; N % 128; K < 256
-    assert lib.ll_gemm_plan_epi(L, Cw, Cw, 0, 0, 1, 0, None, 0) == -1
+    assert lib.ll_gemm_plan_epi(L, Cw, Cw, 0, 0, 1, None, 0) == -1
     try:
         assert lib.ll_set_tuning(b"gemm_asm", 0) == 0
         assert plan(L, F1, Cw, 0, 1, 1).startswith("gemm_kernel_v5")
     finally:
         assert lib.ll_set_tuning(b"gemm_asm", 3) == 0
-    for key in (b"attn_asm", b"attn_asm_min_keys", b"gemm_asm", b"attn_mfma16", b"gemm_splitk_fault"):
-        assert lib.ll_set_tuning(key, {b"attn_asm": 1, b"attn_asm_min_keys": 512, b"gemm_asm": 3}.get(key, 0)) == 0, key
-    assert lib.ll_set_tuning(b"no_such_key", 1) == -1
+    for key in (b"attn_asm", b"attn_asm_min_keys", b"gemm_asm"):
+        assert lib.ll_set_tuning(key, {b"attn_asm": 1, b"attn_asm_min_keys": 512, b"gemm_asm": 3}[key]) == 0, key
+    for gone in (b"no_such_key", b"attn_mfma16", b"attn_sk_wgs", b"gemm_ws", b"gemm_splitk_l2"):      # pruned in round 4: experiments/
+        assert lib.ll_set_tuning(gone, 1) == -1, gone
 
 
 def test_ops_refuse_cpu_tensors():

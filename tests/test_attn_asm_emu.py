@@ -32,21 +32,41 @@ def bf16_val(bits):
     return E.bf16_to_f32(np.asarray(bits, dtype=np.uint32))
 
 
-def run_case(text, mode, rows_valid, nkeys, seed=0, spikes=(), nheads=2, head=1, kstart=3):
-    """One workgroup: 256 query-row slots of which rows_valid exist, keys [kstart, kstart + nkeys) of a cache with nheads heads."""
+def run_case(text, mode, rows_valid, nkeys, seed=0, spikes=(), nheads=2, head=1, kstart=3, qnorm=False, eps=1e-6):
+    """One workgroup: 256 query-row slots of which rows_valid exist, keys [kstart, kstart + nkeys) of a cache with nheads heads.
+    qnorm: `text` is the QNORM form -- q is the raw projection output, RMS-normalised over all nheads * 128 channels in the kernel's
+    prologue from per-(128-column plane, row) sums of squares (what gemm_asm_128_bias_ssq leaves), times a bf16 weight."""
     rng = np.random.default_rng(seed)
     D = 128
     ldq = ldo = ldk = nheads * D
     nq = rows_valid
     q = rng.standard_normal((nq, nheads, D)).astype(np.float32)
+    if qnorm:
+        q = (q * (0.5 + 2.0 * rng.random((nq, 1, 1)))).astype(np.float32)           # rows of different norms
+        qraw = bf16_val(bf16_bits(q)).astype(np.float32)
+        planes = (qraw.astype(np.float64) ** 2).sum(axis=2).T.astype(np.float32).copy()      # [nheads planes][nq]: exactly the valid rows
+        wn = bf16_val(bf16_bits(1.0 + 0.1 * rng.standard_normal((nheads, D)))).astype(np.float32)
+        ss = np.zeros(nq, dtype=np.float32)
+        for j in range(nheads):                       # plane order, fp32, as the kernel sums
+            ss = (ss + planes[j]).astype(np.float32)
+        rinv = (1.0 / np.sqrt((ss.astype(np.float64) * np.float64(np.float32(1.0 / (nheads * D)))).astype(np.float32).astype(np.float64)
+                              + np.float64(np.float32(eps)))).astype(np.float32)
+        t1 = bf16_val(bf16_bits(qraw * rinv[:, None, None])).astype(np.float32)
+        q_eff = bf16_val(bf16_bits(t1 * wn[None])).astype(np.float32)                # what the rmsnorm kernel would have written
+    qsrc = q
     cache_rows = kstart + nkeys                      # the cache ENDS at the last key: anything past it is out of bounds
     k = rng.standard_normal((cache_rows, nheads, D)).astype(np.float32)
     v = (0.7 * rng.standard_normal((cache_rows, nheads, D))).astype(np.float32)
     for (qi, ki, amp) in spikes:
         k[kstart + ki, head] = amp * q[qi, head]
+    if qnorm:
+        for (qi, ki, amp) in spikes:                  # spikes relative to the NORMALISED query
+            k[kstart + ki, head] = amp * q_eff[qi, head]
     qb_, kb_, vb_ = bf16_bits(q), bf16_bits(k), bf16_bits(v)
     mem = E.Memory()
     aq, ak, av = mem.alloc(qb_), mem.alloc(kb_), mem.alloc(vb_)
+    if qnorm:
+        assq, anw = mem.alloc(planes), mem.alloc(bf16_bits(wn))
     ao = mem.alloc(np.full((nq, nheads, D), 0x7FC0, dtype=np.uint16))
     m = E.Machine(text, mem, 4, mode=mode)
     scale = 1.0 / math.sqrt(D)
@@ -67,12 +87,19 @@ def run_case(text, mode, rows_valid, nkeys, seed=0, spikes=(), nheads=2, head=1,
         s[G.S_ROWS], s[G.S_NT], s[G.S_LASTV] = rows_valid, nt, lastv
         s[G.S_C] = int(E.f2u(c))
         s[G.S_NREC] = (nkeys - 1) * ldk * 2 + D * 2
+        if qnorm:
+            put64(G.S_SSQ, assq)
+            put64(G.S_NW, anw + head * D * 2)
+            s[G.S_SSQ_STRIDE], s[G.S_NPART] = nq * 4, nheads
+            s[G.S_INVC], s[G.S_EPS] = int(E.f2u(np.float32(1.0 / (nheads * D)))), int(E.f2u(np.float32(eps)))
         wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
         wv.v[1:] = 0x7FC0BEEF                           # uninitialised registers are NaN poison
         wv.a[:] = 0x7FC0BEEF
     steps = m.run()
     out = bf16_val(mem.get(ao).view(np.uint16).reshape(nq, nheads, D)[:, head])
     qf, kf, vf = bf16_val(qb_[:, head]).astype(np.float64), bf16_val(kb_[kstart:, head]).astype(np.float64), bf16_val(vb_[kstart:, head]).astype(np.float64)
+    if qnorm:
+        qf = q_eff[:, head].astype(np.float64)
     sc = (qf @ kf.T) * scale
     p = np.exp(sc - sc.max(axis=1, keepdims=True))
     ref = (p / p.sum(axis=1, keepdims=True)) @ vf
@@ -143,3 +170,38 @@ def test_random_geometries(kernel_text):
                                       kstart=int(rng.integers(0, 70)))
         err = np.abs(out - ref).max()
         assert np.isfinite(out).all() and err < 2.5e-2, (rows, nkeys, mode, spikes, err)
+
+
+# ---- QNORM form: RMSNorm of q in the prologue (cross-attention: model.py:172) ---------------------------------------------------
+@pytest.fixture(scope="module")
+def qn_text():
+    return G.generate("buffer", "LLBN", False, True)
+
+
+def test_qnorm_text_is_lint_clean_and_assembles(qn_text, tmp_path):
+    assert G.lint(qn_text) == []
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm assembler here")
+    src = tmp_path / "k.s"
+    src.write_text('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n.text\nkernel:\n' + qn_text)
+    r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "k.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:2000]
+
+
+@pytest.mark.parametrize("rows,nkeys,nheads,head,mode", [(256, 8 * 64, 2, 1, "lazy"), (72, 5 * 64 + 9, 3, 0, "eager"), (200, 2 * 64, 12, 7, "mixed")])
+def test_qnorm_prologue(qn_text, rows, nkeys, nheads, head, mode):
+    """q normalised in the kernel (sum of the planes in plane order, rsq(sum / C + eps), bf16(bf16(x rinv) w), then the pre-scale)
+    against fp64 attention over the separately normalised q: the same bound as the plain form.  12 planes = the 1.3B model's
+    N / 128; rows past the valid ones and planes past S_NPART are never read (the buffers are sized exactly)."""
+    out, ref, steps, m = run_case(qn_text, mode, rows_valid=rows, nkeys=nkeys, seed=11, nheads=nheads, head=head, qnorm=True)
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < 1.2e-2, err
+
+
+def test_qnorm_rescale_path(qn_text):
+    spikes = [(5, 6 * 64 + 10, 3.0), (40, 200, 2.5), (200, 130, 3.0)]
+    out, ref, steps, m = run_case(qn_text, "lazy", rows_valid=256, nkeys=7 * 64, seed=5, spikes=spikes, qnorm=True)
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < 2e-2, err

@@ -41,6 +41,8 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
     gate = bf(0.5 * rng.standard_normal((nframes, N)))
     mem = E.Memory()
     partial = epi == G.EPI_PARTIAL
+    ssq = epi == G.EPI_BIAS_SSQ
+    assq = mem.alloc(np.full(rows_valid, np.nan, dtype=np.float32)) if ssq else 0      # exactly the valid rows: a store past M raises
     # row strides larger than the row (ldx > K, ldo > N: column slices of wider tensors); the padding holds NaN patterns
     xs = np.full((rows_valid, K + xpad), 0x7FC0, dtype=np.uint16); xs[:, :K] = x
     rs = np.full((rows_valid, N + ypad), 0x7FC0, dtype=np.uint16); rs[:, :N] = res
@@ -56,11 +58,15 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
         s[G.S_ROWS], s[G.S_COLS], s[G.S_NK] = rows_valid, N, K // 64
         s[G.S_FLEN], s[G.S_GSTRIDE], s[G.S_M0] = frame_len, N * 2, m0
         s[G.S_ROWLO] = row_lo
+        if ssq:
+            put64(G.S_SSQ, assq)
         wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
         wv.v[1:] = 0x7FC0BEEF
         wv.a[:] = 0x7FC0BEEF
     m.run()
     acc = (f32(x).astype(np.float64) @ f32(w).astype(np.float64).T).astype(np.float32)
+    if ssq:
+        run_case.last_ssq = mem.get(assq).view(np.float32).copy()
     if partial:                                       # one K-range of a split-K call: the fp32 accumulators as they stand
         yfull = mem.get(ay).view(np.float32).reshape(rows_valid, N + ypad)
         assert np.isnan(yfull[:, N:]).all(), "the kernel wrote past its N columns"
@@ -69,7 +75,7 @@ def run_case(WN, epi, mode, rows_valid=200, K=448, seed=0, m0=300, frame_len=130
     assert (yfull[:, N:] == 0x7FC0).all(), "the kernel wrote past its N columns"
     got = f32(yfull[:, :N]).astype(np.float64)
     v = rbf(acc + f32(bias)[None, :])
-    if epi == G.EPI_BIAS:
+    if epi in (G.EPI_BIAS, G.EPI_BIAS_SSQ):
         want = v
     elif epi == G.EPI_GELU:
         xx = v.astype(np.float32)
@@ -135,6 +141,19 @@ def test_gemm_asm_partial_sums_for_split_k():
     """EPI_PARTIAL: the kernel of the small-M split-K path stores its fp32 accumulators (rows past M untouched)."""
     got, want = run_case(128, G.EPI_PARTIAL, "lazy", rows_valid=100, K=512)
     assert np.isfinite(got).all() and np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("rows_valid,mode", [(200, "lazy"), (256, "mixed"), (33, "eager")])
+def test_gemm_asm_row_sums_of_squares(rows_valid, mode):
+    """EPI_BIAS_SSQ: the bias epilogue + ssq[row] = sum over the tile's 128 columns of the ROUNDED outputs squared (the statistics
+    of the RMSNorm that follows the projection: model.py:78-86 after :172).  The outputs equal the bias kernel's; the sums are the
+    fp32 sums of exactly those bf16 values (any order: compared to an fp64 sum), rows past M are never written."""
+    got, want = run_case(128, G.EPI_BIAS_SSQ, mode, rows_valid=rows_valid, K=448)
+    plain, _ = run_case(128, G.EPI_BIAS, mode, rows_valid=rows_valid, K=448)
+    assert np.array_equal(got, plain)
+    ss = run_case.last_ssq.astype(np.float64)
+    ref = (got ** 2).sum(axis=1)
+    assert np.isfinite(ss).all() and np.abs(ss - ref).max() <= 2e-6 * ref.max(), np.abs(ss - ref).max()
 
 
 def test_gemm_asm_row_strides_wider_than_the_rows():

@@ -530,6 +530,7 @@ class Machine:
     def i_v_max3_f32(self, w, i): self._fl(w, i, lambda a, b, c: np.fmax(np.fmax(a, b), c), 3)
     def i_v_exp_f32(self, w, i): self._fl(w, i, lambda a: np.exp2(a.astype(np.float64)).astype(np.float32), 1)
     def i_v_rcp_f32(self, w, i): self._fl(w, i, lambda a: (1.0 / a.astype(np.float64)).astype(np.float32), 1)
+    def i_v_rsq_f32(self, w, i): self._fl(w, i, lambda a: (1.0 / np.sqrt(a.astype(np.float64))).astype(np.float32), 1)
     def i_v_log_f32(self, w, i): self._fl(w, i, lambda a: np.log2(a.astype(np.float64)).astype(np.float32), 1)
 
     def i_v_cvt_pk_bf16_f32(self, w, i):
@@ -552,6 +553,15 @@ class Machine:
 
     def i_v_pk_mul_f32(self, w, i): self._pk(w, i, lambda a, b: a * b)
     def i_v_pk_add_f32(self, w, i): self._pk(w, i, lambda a, b: a + b)
+
+    def i_v_pk_fma_f32(self, w, i):
+        d, a, b, c = i.ops
+        def part(op, k):
+            return u2f(self.rv(w, Op(op.kind, op.idx + k, 1, op.val)) if op.kind != "imm" else self.rv(w, op)).astype(np.float64)
+        with np.errstate(all="ignore"):
+            lo, hi = part(a, 0) * part(b, 0) + part(c, 0), part(a, 1) * part(b, 1) + part(c, 1)      # fused: one rounding
+        self.wv(w, d, f2u(lo.astype(np.float32)), 0)
+        self.wv(w, d, f2u(hi.astype(np.float32)), 1)
 
     def i_v_cvt_f32_u32(self, w, i): self._valu(w, i, lambda a: f2u(a.astype(np.float32)), 1)
     def i_v_cvt_f32_i32(self, w, i): self._valu(w, i, lambda a: f2u(a.view(np.int32).astype(np.float32)), 1)

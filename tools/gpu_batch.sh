@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
+#   layerseq[=N] | layerexp | seqtrace=<env> | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -20,7 +20,8 @@ except Exception as e:
     print("no bench line:", e); sys.exit(0)
 t = r.get("telemetry") or {}
 g = t.get("gpu_metrics_delta") or {}
-print(f"{r['value']:.2f} {r['unit']}  ms/step {r['ms_per_step']:.2f}  roofline frac {r['roofline']['frac']:.4f} avg_us {r['roofline'].get('avg_us', 0):.1f}  "
+rf = r.get("roofline") or {}
+print(f"{r['value']:.2f} {r['unit']}  ms/step {r['ms_per_step']:.2f}  roofline frac {rf.get('frac', 0):.4f} avg_us {rf.get('avg_us', 0):.1f}  "
       f"sclk {t.get('sclk_mhz_avg', 0):.0f} MHz  power {t.get('power_w_avg', 0):.0f} W  ppt {g.get('ppt_residency_acc', 0) / max(1, g.get('accumulation_counter', 1)):.2f}")
 PY
 }
@@ -74,6 +75,18 @@ for step in "$@"; do
     abseq)
       a=$(echo "$arg" | cut -d/ -f1); b=$(echo "$arg" | cut -d/ -f2); rc=0
       for i in 1 2 3; do for t in "$a" "$b"; do echo -n "[$t] "; LL_TUNING=$t timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break 2; }; done; done | tee -a $O/abseq.txt ;;
+    seqtrace)      # per-kernel durations of the layer sequence under timing-only switches: seqtrace="KB_SKIP=0,10"  (kernel trace of tools/kbench layerseq)
+      tag=$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_'); rc=0
+      env $arg timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/seqtrace_$tag -- ./tools/kbench layerseq 300 > $O/seqtrace_$tag.log 2>&1; rc=$?
+      grep layerseq $O/seqtrace_$tag.log | tail -1
+      S=$(ls $O/seqtrace_$tag/*/*kernel_stats.csv 2>/dev/null | head -1)
+      [ -n "$S" ] && python3 - "$S" <<'PY' | tee $O/seqtrace_$tag.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print("  %-64.64s calls %5s avg %9.1f us  total %8.1f ms" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+      rm -f $O/seqtrace_$tag/*/*kernel_trace.csv $O/seqtrace_$tag/*/*.db ;;
     kbench)
       timeout -k 10 300 ./tools/kbench $arg 2>&1 | tee -a $O/kbench.txt; rc=${PIPESTATUS[0]} ;;
     configs)

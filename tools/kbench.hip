@@ -149,25 +149,12 @@ static void bench_gemm_i8(const char* name, int M, int N, int K, int iters) {
   hipFree(xq); hipFree(wq); hipFree(sx); hipFree(sw);
 }
 
-static void* g_ws = nullptr;
-static long long g_ws_bytes = 0;
-static void ensure_ws() {
-  long long need = ll_flash_attn_workspace_bytes();
-  if (getenv("KBENCH_NO_WS")) { g_ws = nullptr; g_ws_bytes = 0; return; }
-  if (need > g_ws_bytes) {
-    if (g_ws) CK(hipFree(g_ws));
-    CK(hipMalloc(&g_ws, need));
-    g_ws_bytes = need;
-  }
-}
-
 static void bench_attn(const char* name, int Lq, int H, int Sk, int n0, int iters) {
-  ensure_ws();
   Buf q((size_t)Lq * H * 128, 1.0f), k((size_t)Sk * H * 128, 1.0f), v((size_t)Sk * H * 128, 0.7f), o((size_t)Lq * H * 128, 0.f);
   hipStream_t s = 0;
   float scale = 1.0f / sqrtf(128.f);
   auto fn = [&]() {
-    LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, Lq, H, H * 128, H * 128, H * 128, (long long)Sk * H * 128, 0, n0, 0, 0, scale, g_ws, g_ws_bytes, s));
+    LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, Lq, H, H * 128, H * 128, H * 128, (long long)Sk * H * 128, 0, n0, 0, 0, scale, s));
   };
   double ms = time_ms(s, iters, fn);
   o.pull();
@@ -220,39 +207,30 @@ static void bench_shipped(int iters) {
     Buf x((size_t)L * g.K, 1.0f), w((size_t)g.N * g.K, 1.0f / sqrtf((float)g.K)), bias(g.N, 0.1f), out((size_t)L * g.N, 0.f);
     Buf res((size_t)L * g.N, 1.0f), e((size_t)3 * 6 * g.N, 0.5f);
     const bool qkv = !strcmp(g.tag, "gemm_qkv");
-    const bool sk = !strcmp(g.tag, "gemm_f2") && !getenv("KBENCH_NO_SPLITK") && ll_gemm_splitk_plan(L, g.N, g.K, 0) == 1;
-    void* skws = nullptr;
-    long long skb = sk ? ll_gemm_splitk_workspace_bytes(L, g.N) : 0;
-    if (sk) { CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb)); }
     double ms = time_ms(s, iters, [&]() {
       if (qkv)      // as shipped: the V third goes straight into the KV cache
         LL(ll_gemm_bf16_qkv(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, vcache.d, 1, L, S, S - L, 0, L, s));
-      else if (sk)  // as shipped: FFN2 = 256x256 tiles x split-K 2
-        LL(ll_gemm_bf16_splitk(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, nullptr, 6, 2, L, FS, skws, skb, s));
       else          // as shipped: `e` is a layer's slice of ll_modulation_table (mod = NULL)
         LL(ll_gemm_bf16(x.d, w.d, bias.d, out.d, L, g.N, g.K, g.K, g.N, g.epi, res.d, e.d, nullptr, 6, 2, L, FS, s));
     });
-    if (skws) CK(hipFree(skws));
-    LL(ll_gemm_plan(L, g.N, g.K, 0, plan, sizeof plan));
-    if (sk) snprintf(plan, sizeof plan, "gemm_kernel_v4sk<bf16> tile 256x256 x split-K 2, 228 workgroups");
+    LL(ll_gemm_plan_epi(L, g.N, g.K, 0, g.epi, qkv ? 2 : 1, plan, sizeof plan));
     double fl = 2.0 * L * g.N * g.K, by = 2.0 * ((double)L * g.K + (double)g.N * g.K + (double)L * g.N * (g.epi >= 2 ? 2 : 1));
     printf("%-10s %-60s %8.1f us %7.1f TFLOP/s\n", g.tag, plan, ms * 1e3, fl / (ms * 1e-3) / 1e12);
     char match[64];
-    snprintf(match, sizeof match, sk ? "%.16s<%d" : "%.14s<%d", plan, g.epi);      // gemm_kernel_vN<EPI / gemm_kernel_v4sk<EPI
+    snprintf(match, sizeof match, "%.14s<%d", plan, g.epi);      // gemm_kernel_vN<EPI
     work_line(g.tag, match, fl, by, ms * 1e3, "mfma");
   }
   {
     Buf q((size_t)L * C, 1.0f), k((size_t)S * C, 1.0f), v((size_t)S * C, 0.7f), o((size_t)L * C, 0.f);
     float scale = 1.0f / sqrtf(128.f);
-    ensure_ws();
-    double ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, L, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, g_ws, g_ws_bytes, s)); });
-    LL(ll_flash_attn_plan(L, H, 1, S, 0, 1, g_ws != nullptr, plan, sizeof plan));
+      double ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, k.d, v.d, o.d, 1, L, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, s)); });
+    LL(ll_flash_attn_plan(L, H, 1, S, 0, 1, plan, sizeof plan));
     double fl = 4.0 * L * (double)S * 128 * H;
     printf("%-10s %-60.60s %8.1f us %7.1f TFLOP/s\n", "attn_self", plan, ms * 1e3, fl / (ms * 1e-3) / 1e12);
-    work_line("flash_attn_self", strstr(plan, "flash_attn_sk") ? "flash_attn_sk_kernel<8>" : "flash_attn_pipe_kernel<8, 1>", fl,
+    work_line("flash_attn_self", strstr(plan, "flash_attn_asm") ? "flash_attn_asm_kernel" : "flash_attn_pipe_kernel<8, 1>", fl,
               2.0 * (2.0 * L * C + 2.0 * S * C), ms * 1e3, "mfma");
     Buf kc((size_t)512 * C, 1.0f), vc((size_t)512 * C, 0.7f);
-    ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, kc.d, vc.d, o.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, g_ws, g_ws_bytes, s)); });
+    ms = time_ms(s, iters, [&]() { LL(ll_flash_attn(q.d, kc.d, vc.d, o.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, s)); });
     fl = 4.0 * L * 512.0 * 128 * H;
     printf("%-10s %-60.60s %8.1f us %7.1f TFLOP/s\n", "attn_cross", "flash_attn_pipe_kernel<8, 0> (512 text keys)", ms * 1e3, fl / (ms * 1e-3) / 1e12);
     work_line("flash_attn_cross", "flash_attn_pipe_kernel<8, 0>", fl, 2.0 * (2.0 * L * C + 2.0 * 512 * C), ms * 1e3, "mfma");
@@ -305,10 +283,7 @@ static void bench_layerseq(int layers) {
   std::vector<float> hrf((size_t)1024 * 22 * 2, 0.5f), hrhw((size_t)FS * 42 * 2, 0.5f);
   CK(hipMalloc(&rf, hrf.size() * 4)); CK(hipMalloc(&rhw, hrhw.size() * 4));
   CK(hipMemcpy(rf, hrf.data(), hrf.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(rhw, hrhw.data(), hrhw.size() * 4, hipMemcpyHostToDevice));
-  long long skb = ll_gemm_splitk_workspace_bytes(L, C);
-  void* skws; CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb));
   const float scale = 1.0f / sqrtf(128.f);
-  ensure_ws();
   // TIMING-ONLY experiment switches (what a fusion or a balanced grid could buy, before building it):
   //   KB_SKIP=i,j,...   leave launches i, j, ... (0-based, model order) out of the layer
   //   KB_ATTN_LQ / KB_ATTN_S   geometry of the self-attention launch (e.g. 5376 rows x 17024 keys = 252 workgroups x 266 key tiles:
@@ -320,21 +295,29 @@ static void bench_layerseq(int layers) {
   uint16_t* aq = aLq > L ? qbig.d : q.d;
   uint16_t* ao = aLq > L ? obig.d : att.d;
   if (skip || aLq != L || aS != S) printf("layerseq: TIMING-ONLY experiment (skip mask 0x%x, self-attention %d rows x %d keys)\n", skip, aLq, aS);
+  // KB_FUSE_QN=0: the three-launch form of cross-attention's q path (projection, RMSNorm, attention) instead of the shipped two
+  const bool fuse_qn = !(getenv("KB_FUSE_QN") && atoi(getenv("KB_FUSE_QN")) == 0) && ll_gemm_ssq_planes(L, C, C) == H && ll_flash_attn_qnorm_ok(H, 512);
+  float* ssq; CK(hipMalloc(&ssq, (size_t)H * L * 4)); CK(hipMemset(ssq, 0, (size_t)H * L * 4));
 #define ON(i) (!(skip & (1u << (i))))
   auto layer = [&]() {
     if (ON(0)) LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 0, 1, 1, L, C, 3, 1e-6f, s));
     if (ON(1)) LL(ll_gemm_bf16_qkv(h.d, wqkv.d, bqkv.d, qkv.d, L, 3 * C, C, C, 3 * C, vc.d, 1, L, S, S - L, 0, L, s));
     if (ON(2)) LL(ll_qk_norm_rope_kv_store(qkv.d, nw.d, nw.d, rf, rhw, q.d, kc.d, nullptr, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
-    if (ON(3)) LL(ll_flash_attn(aq, kc.d, vc.d, ao, 1, aLq, H, C, C, C, (long long)S * C, 0, aS, 0, 0, scale, g_ws, g_ws_bytes, s));
+    if (ON(3)) LL(ll_flash_attn(aq, kc.d, vc.d, ao, 1, aLq, H, C, C, C, (long long)S * C, 0, aS, 0, 0, scale, s));
     if (ON(4)) LL(ll_gemm_bf16(att.d, wo.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 2, L, FS, s));
     if (ON(5)) LL(ll_layernorm_affine(xs.d, nw.d, nb.d, h.d, L, C, 1e-6f, s));
-    if (ON(6)) LL(ll_gemm_bf16(h.d, wcq.d, bo.d, q.d, L, C, C, C, C, LL_EPI_BIAS, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
-    if (ON(7)) LL(ll_rmsnorm(q.d, nw.d, q.d, L, C, C, C, 1e-6f, s));
-    if (ON(8)) LL(ll_flash_attn(q.d, ck.d, cv.d, att.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, g_ws, g_ws_bytes, s));
+    if (fuse_qn) {      // cross-attention q: RMSNorm statistics from the projection's epilogue, applied in the attention prologue (2 launches)
+      if (ON(6)) LL(ll_gemm_bf16_ssq(h.d, wcq.d, bo.d, q.d, ssq, L, C, C, C, C, s));
+      if (ON(8)) LL(ll_flash_attn_qnorm(q.d, ssq, nw.d, 1e-6f, ck.d, cv.d, att.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, scale, s));
+    } else {
+      if (ON(6)) LL(ll_gemm_bf16(h.d, wcq.d, bo.d, q.d, L, C, C, C, C, LL_EPI_BIAS, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
+      if (ON(7)) LL(ll_rmsnorm(q.d, nw.d, q.d, L, C, C, C, 1e-6f, s));
+      if (ON(8)) LL(ll_flash_attn(q.d, ck.d, cv.d, att.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, s));
+    }
     if (ON(9)) LL(ll_gemm_bf16(att.d, wco.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_RES, xs.d, nullptr, nullptr, 0, 0, 0, 0, s));
     if (ON(10)) LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 3, 4, 1, L, C, 3, 1e-6f, s));
     if (ON(11)) LL(ll_gemm_bf16(h.d, w1.d, b1.d, ffh.d, L, F1, C, C, F1, LL_EPI_BIAS_GELU, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
-    if (ON(12)) LL(ll_gemm_bf16_splitk(ffh.d, w2.d, b2.d, xs.d, L, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 5, L, FS, skws, skb, s));
+    if (ON(12)) LL(ll_gemm_bf16(ffh.d, w2.d, b2.d, xs.d, L, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 5, L, FS, s));
   };
 #undef ON
   for (int i = 0; i < 3; ++i) layer();
@@ -344,8 +327,8 @@ static void bench_layerseq(int layers) {
   for (int i = 0; i < layers; ++i) layer();
   CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("layerseq: %d layers, %.1f us per layer (13 launches in model order; 150 layers = one AR block: %.1f ms)\n", layers, ms * 1e3 / layers, ms * 150.0 / layers);
-  hipFree(rf); hipFree(rhw); hipFree(skws);
+  printf("layerseq: %d layers, %.1f us per layer (%d launches in model order; 150 layers = one AR block: %.1f ms)\n", layers, ms * 1e3 / layers, fuse_qn ? 12 : 13, ms * 150.0 / layers);
+  hipFree(rf); hipFree(rhw); hipFree(ssq);
 }
 
 int main(int argc, char** argv) {

@@ -89,9 +89,7 @@ int main(int argc, char** argv) {
     auto* v = (ll_bf16*)dalloc((size_t)Lk * H * 128 * 2, 0.7f);
     auto* o = (ll_bf16*)dalloc((size_t)M * H * 128 * 2, 0.f);
     float scale = 1.0f / sqrtf(128.f);
-    long long ws_bytes = getenv("KENERGY_NO_WS") ? 0 : ll_flash_attn_workspace_bytes();
-    void* ws = ws_bytes ? dalloc((size_t)ws_bytes, 0.f) : nullptr;
-    fn = [=]() { LL(ll_flash_attn(q, k, v, o, 1, M, H, H * 128, H * 128, H * 128, (long long)Lk * H * 128, 0, Lk, 0, 0, scale, ws, ws_bytes, s)); };
+    fn = [=]() { LL(ll_flash_attn(q, k, v, o, 1, M, H, H * 128, H * 128, H * 128, (long long)Lk * H * 128, 0, Lk, 0, 0, scale, s)); };
     flops = 4.0 * M * Lk * H * 128;
   } else {
     if (variant > 0) LL(ll_set_tuning("gemm_variant", variant));
@@ -102,14 +100,7 @@ int main(int argc, char** argv) {
     auto* res = (ll_bf16*)dalloc((size_t)M * N * 2, 1.0f);
     auto* e = (ll_bf16*)dalloc((size_t)3 * 6 * N * 2, 0.5f);
     auto* mod = (ll_bf16*)dalloc((size_t)6 * N * 2, 0.1f);
-    void* skws = nullptr;
-    long long skb = 0;
-    if (getenv("KENERGY_SPLITK")) {        // FFN2 as shipped: 256x256 tiles x split-K 2 (ll_gemm_bf16_splitk)
-      skb = ll_gemm_splitk_workspace_bytes(M, N);
-      if (skb > 0) { CK(hipMalloc(&skws, (size_t)skb)); CK(hipMemset(skws, 0, (size_t)skb)); }
-    }
-    if (skws) fn = [=]() { LL(ll_gemm_bf16_splitk(x, w, b, out, M, N, K, K, N, epi, res, e, mod, 6, 2, M, M / 3, skws, skb, s)); };
-    else fn = [=]() { LL(ll_gemm_bf16(x, w, b, out, M, N, K, K, N, epi, res, e, getenv("KENERGY_MOD") ? mod : nullptr, 6, 2, M, M / 3, s)); };
+    fn = [=]() { LL(ll_gemm_bf16(x, w, b, out, M, N, K, K, N, epi, res, e, getenv("KENERGY_MOD") ? mod : nullptr, 6, 2, M, M / 3, s)); };
     flops = 2.0 * M * N * K;
   }
   for (int i = 0; i < 10; ++i) fn();
