@@ -113,6 +113,7 @@ def knobs_header(path):
 
 
 LSUM = KNOB("LSUM", 0)                       # 1: row sums by the matrix pipe (ones-MFMA into LACC); 0: by v_add_f32 into 4 partials per q-block
+PK_LSUM = KNOB("PK_LSUM", 0)                 # LSUM = 0: row sums by v_pk_add_f32 on element pairs (two pair-accumulators per q-block) instead of v_add_f32 per element
 ADD_LATE = KNOB("ADD_LATE", 0)               # LSUM = 0: the adds of the elements whose registers survive the in-place pack (registers
                                              # 8..15 of every score tile) are issued in phase B instead of phase A
 S_TS, S_ACC = 60, 64                         # last stamp s[60:61]; sums s[64:65] A, s[66:67] B, s[68:69] wait+barrier, s[70:71] whole loop
@@ -260,7 +261,12 @@ def finish_ops(y, with_pos=False):
         if not LSUM and 2 <= t < n + 2:
             qb, r, _, j = elems[t - 2]
             late = ADD_LATE and (r & 15) >= 8
-            ops.append((t if not late else 1000 + t, f"v_add_f32 {vreg(V_L + 4 * qb + (j & 3))}, {vreg(V_L + 4 * qb + (j & 3))}, {vreg(r)}"))
+            if PK_LSUM:                                   # one packed add per PAIR of elements (after the second one's exp): 32 instead of 64 per tile
+                if j & 1:
+                    a = V_L + 4 * qb + 2 * ((j >> 1) & 1)
+                    ops.append((t if not late else 1000 + t, f"v_pk_add_f32 {vreg(a, 2)}, {vreg(a, 2)}, {vreg(r - 1, 2)}"))
+            else:
+                ops.append((t if not late else 1000 + t, f"v_add_f32 {vreg(V_L + 4 * qb + (j & 3))}, {vreg(V_L + 4 * qb + (j & 3))}, {vreg(r)}"))
         if t >= DC and (t - DC) % 2 == 0 and t - DC < n:
             qb, r0, dst, j = elems[t - DC]
             ops.append((t, f"v_cvt_pk_bf16_f32 {vreg(dst)}, {vreg(r0)}, {vreg(r0 + 1)}"))

@@ -267,8 +267,8 @@ class CausalWanModelHIP(nn.Module):
         """[B, text_len, text_dim] -> [B, text_len, C]   (causal_model.py:984-989).  The reference recomputes this
         every forward; its only consumer is the cross-attention K/V projection, which is cached per prompt
         (model.py:174-183), so it is evaluated lazily and memoised on the prompt tensor."""
-        key = (context.data_ptr(), context._version)
-        if self._ctx_cache is not None and self._ctx_cache[:2] == key:
+        key = (context.data_ptr(), (context._version, torch.cuda.current_stream(context.device).cuda_stream if context.is_cuda else 0))
+        if self._ctx_cache is not None and self._ctx_cache[:2] == key:      # (same prompt tensor AND same HIP stream: the memo was computed there)
             return self._ctx_cache[2]
         c = self.cfg
         ctx = context.to(bf16)

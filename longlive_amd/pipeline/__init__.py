@@ -1,6 +1,7 @@
 from .causal_inference import CausalInferencePipeline
 from .interactive_causal_inference import InteractiveCausalInferencePipeline
 from .streaming_training import StreamingSwitchTrainingPipeline, StreamingTrainingPipeline
+from .throughput import InterleavedStreams
 
-__all__ = ["CausalInferencePipeline", "InteractiveCausalInferencePipeline", "StreamingTrainingPipeline",
+__all__ = ["InterleavedStreams", "CausalInferencePipeline", "InteractiveCausalInferencePipeline", "StreamingTrainingPipeline",
            "StreamingSwitchTrainingPipeline"]

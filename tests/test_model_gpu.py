@@ -288,3 +288,37 @@ def test_two_stream_context_overlap_is_bit_identical():
             assert torch.equal(got[0], base[0]) and got[2] == base[2], (interactive, rep)
             for a, b in zip(got[1], base[1]):
                 assert torch.equal(a, b), (interactive, rep)
+
+
+def test_interleaved_streams_are_bit_identical_to_solo_runs():
+    """Throughput mode (pipeline/throughput.py: BASELINE config 5's several prompts per GPU): two independent prompt streams on two
+    HIP streams of one process, launches interleaved block by block, one shared generator -- every stream's latents, caches and
+    indices equal the same stream run alone, bit for bit (run twice: an ordering that only holds by luck would show)."""
+    from longlive_amd.pipeline import CausalInferencePipeline, InterleavedStreams
+    cfg, gen, enc = _pipe_generator()
+    noises = [synth.synth_noise(cfg, 18, seed=45 + s, device=DEV) for s in (0, 1)]
+    prompts = [enc(text_prompts=[f"p{s}"]) for s in (0, 1)]
+
+    def pipe(s):
+        P = CausalInferencePipeline(_pipe_args(False), DEV, generator=gen)
+        P.randn_like = TD.HashRandn(47 + s)
+        return P
+
+    solo = []
+    for s in (0, 1):
+        P = pipe(s)
+        _, lat = P.inference(noises[s], prompts[s], return_latents=True)
+        torch.cuda.synchronize()
+        solo.append((lat.clone(), [kv["k"].clone() for kv in P.kv_cache1] + [kv["v"].clone() for kv in P.kv_cache1],
+                     (P.kv_cache1[0]["global_end_index"], P.kv_cache1[0]["local_end_index"])))
+    assert not torch.equal(solo[0][0], solo[1][0])
+    for rep in range(2):
+        pipes = [pipe(0), pipe(1)]
+        lats = InterleavedStreams(pipes, DEV).inference(noises, prompts)
+        torch.cuda.synchronize()
+        for s in (0, 1):
+            assert torch.equal(lats[s], solo[s][0]), (rep, s, (lats[s].float() - solo[s][0].float()).abs().max().item())
+            got = [kv["k"] for kv in pipes[s].kv_cache1] + [kv["v"] for kv in pipes[s].kv_cache1]
+            for a, b in zip(got, solo[s][1]):
+                assert torch.equal(a, b), (rep, s)
+            assert (pipes[s].kv_cache1[0]["global_end_index"], pipes[s].kv_cache1[0]["local_end_index"]) == solo[s][2]

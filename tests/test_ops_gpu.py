@@ -574,7 +574,8 @@ def test_synth_hash_kernel_matches_the_tensor_hash():
         synth.FORCE_TORCH_HASH = False
 
 
-@pytest.mark.parametrize("B,L,H,K,Sk", [(1, 520, 12, 1536, 512),      # the 1.3B model's cross-attention shape class: 12 planes, 8 key tiles
+@pytest.mark.parametrize("B,L,H,K,Sk", [(1, 1100, 12, 1536, 512),     # the 1.3B model's cross-attention shape class: 12 planes, 8 key tiles (M > 1024:
+                                                                      # ops.gemm must take the plain kernel too, not the small-M split-K path)
                                         (2, 300, 2, 256, 512),        # batch 2, toy width (2 planes), padded rows + idle waves
                                         (1, 72, 3, 384, 640)])        # the last q-tile of Lq 4680; 3 planes; 10 key tiles
 def test_cross_q_rmsnorm_fused_into_projection_and_attention(ops, B, L, H, K, Sk):

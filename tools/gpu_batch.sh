@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | seqtrace=<env> | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
+#   layerseq[=N] | layerexp | seqtrace=<env> | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -87,6 +87,19 @@ for r in rows[:14]:
     print("  %-64.64s calls %5s avg %9.1f us  total %8.1f ms" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
       rm -f $O/seqtrace_$tag/*/*kernel_trace.csv $O/seqtrace_$tag/*/*.db ;;
+    ablib)         # interleaved A/B of the layer sequence: in-tree library vs a variant built by tools/build_variant.sh (ablib=<name>[/rounds])
+      v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=3; rc=0
+      for i in $(seq 1 $n); do
+        echo -n "[shipped] "; timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
+        echo -n "[$v] "; LD_LIBRARY_PATH=experiments/r04/libs/$v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
+      done | tee -a $O/ablib_$v.txt ;;
+    abbench)       # the same with bench.py: abbench=<name>[/rounds]
+      v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
+      for i in $(seq 1 $n); do for t in "" "experiments/r04/libs/$v/liblonglive_hip.so"; do
+        if [ -z "$t" ]; then timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abb_$i.json 2> $O/abb_$i.err; else LONGLIVE_HIP_LIB=$t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abb_$i.json 2> $O/abb_$i.err; fi
+        rc=$?; dead $rc && break 2
+        echo -n "[${t:-shipped}] "; benchline $O/abb_$i.json
+      done; done | tee -a $O/abbench_$v.txt ;;
     kbench)
       timeout -k 10 300 ./tools/kbench $arg 2>&1 | tee -a $O/kbench.txt; rc=${PIPESTATUS[0]} ;;
     configs)
