@@ -336,12 +336,13 @@ def _plan_text(fn, *a):
     return buf.value.decode()
 
 
-def kernel_table(summary, quant, mod_table=True):
+def kernel_table(summary, quant, mod_table=True, fuse_qn=True):
     """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac)."""
     from longlive_amd import _lib
     lib = _lib.load()
     i8 = 1 if quant == "int8" else 0
     L, C, F1, LK = 4680, 1536, 8960, 18720
+    fused_qn = bool(fuse_qn and not i8 and lib.ll_gemm_ssq_planes(L, C, C) == 12 and lib.ll_flash_attn_qnorm_ok(12, 512))
     gemm_shapes = {"gemm_qkv": (L, 3 * C, C), "gemm_o": (L, C, C), "gemm_cq": (L, C, C), "gemm_co": (L, C, C),
                    "gemm_f1": (L, F1, C), "gemm_f2": (L, C, F1)}
     what = {"gemm_qkv": "self-attn QKV", "gemm_o": "self-attn O + gate-residual", "gemm_cq": "cross-attn Q",
@@ -359,10 +360,14 @@ def kernel_table(summary, quant, mod_table=True):
             # (gate-residual calls when the model runs with use_modulation_table = False: those take the HIP kernels)
             plain = 2 if tag == "gemm_qkv" else (0 if (epi == 2 and not mod_table) else 1)
             name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, plain)
+            if tag == "gemm_cq" and fused_qn:                       # the projection whose epilogue also leaves the RMSNorm's row sums of squares
+                name = name.replace("gemm_asm_128_bias<", "gemm_asm_128_bias_ssq<")
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1)
         elif tag == "flash_attn_cross":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1)
+            if fused_qn:                                            # the form whose Q prologue applies the q RMSNorm (no rmsnorm launch)
+                name = name.replace("flash_attn_asm_kernel", "flash_attn_asm_qn_kernel")
         else:
             name = {"ln_modulate": "ln_modulate_kernel", "layernorm_affine": "layernorm_affine_kernel", "rmsnorm": "rmsnorm_kernel",
                     "qk_norm_rope_kv_store": "qk_norm_rope_kv_kernel", "kv_roll": "copy_rows_kernel",
@@ -657,7 +662,8 @@ def run_replica(args, rank, world, local_rank, sync):
             blk_ms = 1e3 * (time.perf_counter() - t0)
             summ = ops.timer.summary()
             ops.timer = None
-            rows = kernel_table(summ, quant, mod_table=bool(getattr(gen.model, "use_modulation_table", True)))
+            rows = kernel_table(summ, quant, mod_table=bool(getattr(gen.model, "use_modulation_table", True)),
+                                fuse_qn=bool(getattr(gen.model, "fuse_cross_qnorm", True)))
             res["kernels"] = {"note": "one untimed steady-state block, HIP events around every launch (adds ~2 us of gap per launch: "
                                       f"this block took {blk_ms:.1f} ms); shares are of the sum of kernel time",
                               "sum_kernel_ms": sum(r["total_ms"] for r in rows), "rows": rows}
