@@ -47,7 +47,9 @@ const char* ll_last_error(void);
  *   "gemm_asm"  bit 0 = the generated one-wave-per-SIMD GEMM kernels where they cover the call (gemm_asm_224_gelu: FFN1;
  *               gemm_asm_192_bias: QKV with its V-cache redirect; gemm_asm_128_*: N <= 2048 with bias / gate-residual / residual),
  *               bits 2 / 3 = leave the GELU / the 128-wide kernels out, bit 4 (16) = ll_gemm_w8a8 / ll_gemm_w8a8_qkv on the
- *               generated W8A8 kernels too (bit-identical results, measured slower end to end); default 3; 0 = HIP kernels only
+ *               generated W8A8 kernels too (bit-identical results, measured slower end to end), bit 5 (32) = launches with more
+ *               tiles than CUs run the PERSISTENT form (gemm_asmp_*: one workgroup per CU walks its tiles and stages the next
+ *               tile's first pieces under the current epilogue; bit-identical results); default 35; 0 = HIP kernels only
  *   "gemm_variant" / "gemm_variant_wide" (N >= 4096 only)  tile of the HIP kernels (int8, embeddings / head, gemm_asm = 0):
  *               0 = auto (cost model), 2 = 256x128, 3 = 256x256, 5 = 256x192, 6 = 256x224
  *   "gemm_group_m"  m-tiles per group of the GEMM tile walk (default 4; <= 1: N fastest);  "gemm_lds_epi" 0 / 1 / 2 = HIP epilogues

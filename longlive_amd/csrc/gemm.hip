@@ -276,7 +276,8 @@ static int g_gemm_variant_wide = 0;  // like gemm_variant, but only for N >= 409
 // 1: epilogue staged through LDS (whole-line residual loads / stores) in the v2 / v5 tilings, except the GELU epilogue, whose
 // register form measured 1.6 % faster (FFN1 127.2 vs 129.3 us; everything else 1.5-11 % faster staged); 2: all; 0: none
 static int g_gemm_lds_epi = 1;
-static int g_gemm_asm = 3;         // generated kernels where they cover the call, also in place of split-K (see launch_gemm)
+static int g_gemm_asm = 35;        // generated kernels where they cover the call (bits 0, 1), persistent form for multi-round launches (bit 5)
+extern int g_gemm_asm_persistent;
 static int g_gemm_group_m = 4;     // m-tiles per group in the workgroup -> tile walk (tile_of); <= 1: N fastest (round 1's order)
 void ll_set_attn_variant_internal(int v);
 void ll_set_attn_xcd_internal(int v);
@@ -301,7 +302,7 @@ extern "C" int ll_set_tuning(const char* key, int value) {
   if (!strcmp(key, "attn_asm_min_keys")) { ll_set_attn_asm_min_internal(value); return LL_OK; }
   if (!strcmp(key, "attn_asm")) { ll_set_attn_asm_internal(value); return LL_OK; }
   if (!strcmp(key, "conv_halo")) { ll_set_conv_halo_internal(value); return LL_OK; }
-  if (!strcmp(key, "gemm_asm")) { g_gemm_asm = value; return LL_OK; }
+  if (!strcmp(key, "gemm_asm")) { g_gemm_asm = value; g_gemm_asm_persistent = (value & 32) ? 1 : 0; return LL_OK; }
   ll_set_error("ll_set_tuning: unknown key %s", key);
   return LL_ERR_INVALID_ARG;
 }

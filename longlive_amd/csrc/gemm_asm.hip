@@ -47,6 +47,32 @@
 #undef GA_WN
 #undef GA_INC
 
+#define GA_NAME gemm_asmp_224_gelu
+#define GA_INC "build/gemm_asmp_224_1.inc"
+#include "gemm_asm_kernel_p.inl"
+#undef GA_NAME
+#undef GA_INC
+#define GA_NAME gemm_asmp_192_bias
+#define GA_INC "build/gemm_asmp_192_0.inc"
+#include "gemm_asm_kernel_p.inl"
+#undef GA_NAME
+#undef GA_INC
+#define GA_NAME gemm_asmp_128_bias
+#define GA_INC "build/gemm_asmp_128_0.inc"
+#include "gemm_asm_kernel_p.inl"
+#undef GA_NAME
+#undef GA_INC
+#define GA_NAME gemm_asmp_128_gate_res
+#define GA_INC "build/gemm_asmp_128_2.inc"
+#include "gemm_asm_kernel_p.inl"
+#undef GA_NAME
+#undef GA_INC
+#define GA_NAME gemm_asmp_128_res
+#define GA_INC "build/gemm_asmp_128_3.inc"
+#include "gemm_asm_kernel_p.inl"
+#undef GA_NAME
+#undef GA_INC
+
 #define GA_NAME gemm_asm_128_bias_ssq
 #define GA_WN 128
 #define GA_INC "build/gemm_asm_128_5.inc"
@@ -113,6 +139,19 @@
 #undef GA_WN
 #undef GA_INC
 
+int g_gemm_asm_persistent = 1;      // tuning key gemm_asm bit 5 (set from gemm.hip's ll_set_tuning)
+static int gemm_asm_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+
 // tile width of the generated kernel that covers this call, 0 = none (the caller takes the HIP kernels).
 // plain = no int8 scales, no per-batch modulation vector; v_ok = no V-cache output, or one the 192-wide kernel can redirect per
 // tile (one batch element, the V third starting on a tile boundary)
@@ -143,8 +182,19 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
                    : epilogue == LL_EPI_BIAS ? (const void*)gemm_asm_128_bias
                    : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asm_128_gate_res : (const void*)gemm_asm_128_res;
   const int lds = 3 * wn * 128 + 4 * 2 * 8192;      // gen/gemm_asm_gen.py Cfg.lds_bytes: 3 W slots of WN rows x 128 B + 2 X units of 8 KiB per wave
-  if (int rc = ll_lds_attr(fn, lds)) return rc;
   const int ntm = (M + 255) / 256, ntn = N / wn;
+  // persistent form (tuning key gemm_asm bit 5): a launch with more tiles than CUs runs ONE workgroup per CU that walks its tiles and
+  // stages the next tile's first pieces under the current epilogue (FFN1: 760 tiles, QKV: 456, the recache forward's N = 1536
+  // linears: 888) -- one pipeline fill per launch instead of one per round
+  const int cus = gemm_asm_cus() & ~7;
+  const void* pfn = wn == 224 ? (const void*)gemm_asmp_224_gelu
+                    : wn == 192 ? (const void*)gemm_asmp_192_bias
+                    : wn != 128 ? nullptr
+                    : epilogue == LL_EPI_BIAS ? (const void*)gemm_asmp_128_bias
+                    : epilogue == LL_EPI_BIAS_GATE_RES ? (const void*)gemm_asmp_128_gate_res : (const void*)gemm_asmp_128_res;
+  const bool persistent = g_gemm_asm_persistent && pfn != nullptr && cus >= 8 && ntm * ntn > cus;
+  if (persistent) fn = pfn;
+  if (int rc = ll_lds_attr(fn, lds)) return rc;
   const bf16* gate = epilogue == LL_EPI_BIAS_GATE_RES ? ea.e + (size_t)ea.gate_idx * N : nullptr;
   const int gstride = ea.nmod * N * 2;
   bf16* v_out = ea.v_out;
@@ -153,7 +203,7 @@ int gemm_asm_launch(const bf16* x, const bf16* w, bf16* out, int M, int N, int K
   void* args[] = {(void*)&x, (void*)&w, (void*)&ea.bias, (void*)&out, (void*)&ea.res, (void*)&gate, (void*)&M, (void*)&N, (void*)&K,
                   (void*)&ldx, (void*)&ldo, (void*)&ea.frame_len, (void*)&gstride, (void*)&ntm, (void*)&ntn, (void*)&gm,
                   (void*)&v_out, (void*)&v_col0, (void*)&v_C, (void*)&v_shift, (void*)&v_lo, (void*)&v_hi};
-  if (hipLaunchKernel(fn, dim3(ntm * ntn), dim3(256), args, (size_t)lds, s) != hipSuccess) return ll_check_launch("gemm_asm");
+  if (hipLaunchKernel(fn, dim3(persistent ? cus : ntm * ntn), dim3(256), args, (size_t)lds, s) != hipSuccess) return ll_check_launch("gemm_asm");
   return 1;
 }
 
@@ -178,8 +228,13 @@ int gemm_asm_ssq_launch(const bf16* x, const bf16* w, const bf16* bias, bf16* ou
 
 const char* gemm_asm_plan(int M, int N, int wn, int epilogue, char* out, int cap, bool i8) {
   const char* tail = wn == 224 ? "gelu" : wn == 256 ? "bias" : epilogue == LL_EPI_BIAS ? "bias" : epilogue == LL_EPI_BIAS_GATE_RES ? "gate_res" : "res";      // wn == 192: bias
-  snprintf(out, (size_t)cap, "gemm_asm%s_%d_%s<%s> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", i8 ? "q" : "", wn,
-           tail, i8 ? "i8" : "bf16", wn, ((M + 255) / 256) * (N / wn));
+  const int tiles = ((M + 255) / 256) * (N / wn), cus = gemm_asm_cus() & ~7;
+  if (!i8 && g_gemm_asm_persistent && wn != 256 && cus >= 8 && tiles > cus)
+    snprintf(out, (size_t)cap, "gemm_asmp_%d_%s<bf16> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d persistent workgroups "
+             "walk %d tiles, next tile staged under the epilogue", wn, tail, wn, cus, tiles);
+  else
+    snprintf(out, (size_t)cap, "gemm_asm%s_%d_%s<%s> tile 256x%d (4 waves x 64 rows, one wave per SIMD, generated schedule), %d workgroups", i8 ? "q" : "", wn,
+             tail, i8 ? "i8" : "bf16", wn, tiles);
   return out;
 }
 

@@ -60,6 +60,19 @@ V_TID = 0
 NSLOT, XU = 3, 2                                                  # W ring slots (shared, one 64-deep K-step each); X units per wave (private)
 S_XM0 = 30                                                        # LDS base of this wave's X units
 
+# ---- PERSISTENT form (bf16; generate(..., persistent=True)): a workgroup walks tiles S_TILE, S_TILE + S_GRID, ... of the launch and
+# issues the NEXT tile's first staging pieces (W(0..2), X(0..1)) before the current tile's epilogue, so a launch of several rounds
+# (FFN1: 760 tiles, QKV: 456 on 256 CUs) pays one pipeline fill, and the epilogue's VALU time runs over the next tile's staging.
+# Inputs are the MATRIX bases; the per-tile scalars above (S_X ... S_ROWLO, S_LDO) are computed here from the tile index with
+# gemm_common.h's mapping (xcd_remap + tile_of), including the V-cache redirect of the fused QKV projection.
+S_XB, S_WB, S_YB, S_BIASB, S_RESB, S_GATEB = 84, 86, 88, 90, 92, 94      # 64-bit bases: X, W, Y, bias, res, gate table (+ gate_idx * N)
+S_LDO0, S_MM, S_NN = 68, 69, 70                                   # Y / RES row stride in bytes; M; N
+S_TILE, S_GRID, S_NTILES, S_NTM, S_NTN, S_GM = 71, 72, 73, 74, 75, 76     # this workgroup's tile, tile stride, tiles, m-tiles, n-tiles, m-tiles per group (>= 1)
+S_VHI, S_VOUT, S_VCOL0, S_VC2, S_VSHIFT, S_VLO = 77, 78, 80, 81, 82, 83  # V redirect: v_hi; s[78:79] cache_v (0 = none); first V column; cache row stride in
+                                                                  # BYTES; cache row of token 0 (signed); v_lo
+S_XN, S_WN, S_PF, S_ROWSN = 64, 66, 31, 42                        # next tile: X / W bases; 1 = its first pieces are staged; its valid rows
+S_MT, S_NT = 54, 55                                               # (m-tile, n-tile) of the tile being mapped; s[54:61] + S_T0..2 are the mapping's scratch
+
 
 def KN(k):
     """timing-only experiment switches (ASM_G_<k>=1; results are invalid with any of them set): refused without --diag
@@ -176,7 +189,124 @@ def drop_loads(ops):
     return [o for o in ops if not o.startswith("buffer_load")]
 
 
-def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
+def udiv(g: Gen, q, num, den, T):
+    """SGPR q = num / den (unsigned, num < 2^24) for wave-uniform SGPR operands: float estimate on the VALU, one correction each way"""
+    I = g.I
+    I(f"v_cvt_f32_u32 {vreg(T)}, {sreg(num)}")
+    I(f"v_cvt_f32_u32 {vreg(T + 1)}, {sreg(den)}")
+    I(f"v_rcp_f32 {vreg(T + 1)}, {vreg(T + 1)}")
+    I("s_nop 0")
+    I(f"v_mul_f32 {vreg(T)}, {vreg(T)}, {vreg(T + 1)}")
+    I(f"v_cvt_u32_f32 {vreg(T)}, {vreg(T)}")
+    I("s_nop 0")
+    I(f"v_readfirstlane_b32 {sreg(q)}, {vreg(T)}")
+    I("s_nop 0")
+    I(f"s_mul_i32 {sreg(S_T2)}, {sreg(q)}, {sreg(den)}")
+    I(f"s_cmp_gt_u32 {sreg(S_T2)}, {sreg(num)}")                   # estimate one too big
+    I(f"s_cselect_b32 {sreg(S_T2)}, 1, 0")
+    I(f"s_sub_u32 {sreg(q)}, {sreg(q)}, {sreg(S_T2)}")
+    I(f"s_mul_i32 {sreg(S_T2)}, {sreg(q)}, {sreg(den)}")
+    I(f"s_sub_u32 {sreg(S_T2)}, {sreg(num)}, {sreg(S_T2)}")        # remainder so far
+    I(f"s_cmp_ge_u32 {sreg(S_T2)}, {sreg(den)}")                   # estimate one too small
+    I(f"s_cselect_b32 {sreg(S_T2)}, 1, 0")
+    I(f"s_add_u32 {sreg(q)}, {sreg(q)}, {sreg(S_T2)}")
+
+
+def gen_tile_map(g: Gen, tile, T):
+    """S_MT, S_NT <- tile_of(xcd_remap(tile, S_NTILES), S_NTM, S_NTN, S_GM) (gemm_common.h).  Clobbers s[54:61], S_T0..2, v[T:T+1]."""
+    I = g.I
+    q, r, x, hi, q1, a, b, c_ = 54, 55, 56, 57, 58, 59, 60, 61
+    I(f"s_lshr_b32 {sreg(q)}, {sreg(S_NTILES)}, 3")
+    I(f"s_and_b32 {sreg(r)}, {sreg(S_NTILES)}, 7")
+    I(f"s_and_b32 {sreg(x)}, {sreg(tile)}, 7")
+    I(f"s_lshr_b32 {sreg(hi)}, {sreg(tile)}, 3")
+    I(f"s_add_u32 {sreg(q1)}, {sreg(q)}, 1")
+    I(f"s_mul_i32 {sreg(a)}, {sreg(x)}, {sreg(q1)}")                # xcd < r:  xcd * (q + 1)
+    I(f"s_mul_i32 {sreg(b)}, {sreg(r)}, {sreg(q1)}")                # else:     r * (q + 1) + (xcd - r) * q
+    I(f"s_sub_u32 {sreg(c_)}, {sreg(x)}, {sreg(r)}")
+    I(f"s_mul_i32 {sreg(c_)}, {sreg(c_)}, {sreg(q)}")
+    I(f"s_add_u32 {sreg(b)}, {sreg(b)}, {sreg(c_)}")
+    I(f"s_cmp_lt_u32 {sreg(x)}, {sreg(r)}")
+    I(f"s_cselect_b32 {sreg(a)}, {sreg(a)}, {sreg(b)}")
+    I(f"s_add_u32 {sreg(S_T0)}, {sreg(a)}, {sreg(hi)}")             # lid
+    # tile_of: per = gm * ntn; g = lid / per; first = g * gm; gs = min(ntm - first, gm); w = lid - g * per; nt = w / gs; mt = first + w % gs
+    I(f"s_mul_i32 {sreg(S_T1)}, {sreg(S_GM)}, {sreg(S_NTN)}")       # per
+    udiv(g, 56, S_T0, S_T1, T)                                      # s56 = g
+    I(f"s_mul_i32 {sreg(57)}, {sreg(56)}, {sreg(S_T1)}")
+    I(f"s_sub_u32 {sreg(S_T0)}, {sreg(S_T0)}, {sreg(57)}")          # w
+    I(f"s_mul_i32 {sreg(58)}, {sreg(56)}, {sreg(S_GM)}")            # first
+    I(f"s_sub_u32 {sreg(S_T1)}, {sreg(S_NTM)}, {sreg(58)}")
+    I(f"s_min_u32 {sreg(S_T1)}, {sreg(S_T1)}, {sreg(S_GM)}")        # gs
+    udiv(g, S_NT, S_T0, S_T1, T)                                    # nt = w / gs
+    I(f"s_mul_i32 {sreg(57)}, {sreg(S_NT)}, {sreg(S_T1)}")
+    I(f"s_sub_u32 {sreg(57)}, {sreg(S_T0)}, {sreg(57)}")            # w % gs
+    I(f"s_add_u32 {sreg(S_MT)}, {sreg(58)}, {sreg(57)}")
+
+
+def add64(g: Gen, dst, base, lo, hi=None):
+    """s[dst:dst+1] = s[base:base+1] + (hi:lo)   (hi = None: zero-extended lo)"""
+    g.I(f"s_add_u32 {sreg(dst)}, {sreg(base)}, {sreg(lo)}")
+    g.I(f"s_addc_u32 {sreg(dst + 1)}, {sreg(base + 1)}, {sreg(hi) if hi is not None else 0}")
+
+
+def gen_tile_bases(g: Gen, c, xdst, wdst, rows_dst, skip_label, full: bool, prefix: str):
+    """From S_MT / S_NT: X and W bases and the tile's valid rows into the given registers; full: also every other per-tile scalar of
+    the classic kernel's interface (S_Y, S_RES, S_BIAS, S_GATE, S_COLS, S_M0, S_ROWLO, S_LDO) incl. the V-cache redirect.  A V tile
+    with nothing to store branches to skip_label.  Scratch: s[56:61], S_T0..2."""
+    I = g.I
+    m0r, n0 = 56, 57
+    I(f"s_lshl_b32 {sreg(m0r)}, {sreg(S_MT)}, 8")
+    I(f"s_mul_i32 {sreg(n0)}, {sreg(S_NT)}, {c.WN}")
+    I(f"s_mul_i32 {sreg(S_T0)}, {sreg(m0r)}, {sreg(S_LDX)}")
+    I(f"s_mul_hi_u32 {sreg(S_T1)}, {sreg(m0r)}, {sreg(S_LDX)}")
+    add64(g, xdst, S_XB, S_T0, S_T1)
+    I(f"s_mul_i32 {sreg(S_T0)}, {sreg(n0)}, {sreg(S_LDW)}")
+    I(f"s_mul_hi_u32 {sreg(S_T1)}, {sreg(n0)}, {sreg(S_LDW)}")
+    add64(g, wdst, S_WB, S_T0, S_T1)
+    I(f"s_sub_u32 {sreg(rows_dst)}, {sreg(S_MM)}, {sreg(m0r)}")
+    if full:
+        I(f"s_sub_u32 {sreg(S_COLS)}, {sreg(S_NN)}, {sreg(n0)}")
+        I(f"s_mov_b32 {sreg(S_M0)}, {sreg(m0r)}")
+        I(f"s_mov_b32 {sreg(S_ROWLO)}, 0")
+        I(f"s_mov_b32 {sreg(S_LDO)}, {sreg(S_LDO0)}")
+        I(f"s_lshl_b32 {sreg(58)}, {sreg(n0)}, 1")                   # column offset in bytes
+        add64(g, S_BIAS, S_BIASB, 58)
+        add64(g, S_GATE, S_GATEB, 58)
+        I(f"s_mul_i32 {sreg(S_T0)}, {sreg(m0r)}, {sreg(S_LDO0)}")
+        I(f"s_mul_hi_u32 {sreg(S_T1)}, {sreg(m0r)}, {sreg(S_LDO0)}")
+        I(f"s_add_u32 {sreg(S_T0)}, {sreg(S_T0)}, {sreg(58)}")
+        I(f"s_addc_u32 {sreg(S_T1)}, {sreg(S_T1)}, 0")
+        add64(g, S_Y, S_YB, S_T0, S_T1)
+        add64(g, S_RES, S_RESB, S_T0, S_T1)
+    # V tile of the fused QKV projection (gemm_common.h epi_dest): token t -> cache row t + v_shift for v_lo <= t < v_hi
+    g.uid += 1
+    lab = f"{prefix}_NOTV_{g.uid}"
+    I(f"s_cmp_eq_u64 {sreg(S_VOUT, 2)}, 0")
+    I(f"s_cbranch_scc1 {lab}")
+    I(f"s_cmp_lt_u32 {sreg(n0)}, {sreg(S_VCOL0)}")
+    I(f"s_cbranch_scc1 {lab}")
+    I(f"s_min_i32 {sreg(59)}, {sreg(S_MM)}, {sreg(S_VHI)}")
+    I(f"s_sub_i32 {sreg(59)}, {sreg(59)}, {sreg(m0r)}")              # hi = min(M, v_hi) - m0
+    I(f"s_sub_i32 {sreg(60)}, {sreg(S_VLO)}, {sreg(m0r)}")
+    I(f"s_max_i32 {sreg(60)}, {sreg(60)}, 0")                        # lo = max(v_lo - m0, 0)
+    I(f"s_cmp_le_i32 {sreg(59)}, {sreg(60)}")
+    I(f"s_cbranch_scc1 {skip_label}")                                # nothing of this tile is stored
+    I(f"s_mov_b32 {sreg(rows_dst)}, {sreg(59)}")
+    if full:
+        I(f"s_mov_b32 {sreg(S_ROWLO)}, {sreg(60)}")
+        I(f"s_mov_b32 {sreg(S_LDO)}, {sreg(S_VC2)}")
+        I(f"s_add_i32 {sreg(S_T2)}, {sreg(m0r)}, {sreg(S_VSHIFT)}")  # cache row of the tile's first token (may be negative: rows below lo are not stored)
+        I(f"s_mul_i32 {sreg(S_T0)}, {sreg(S_T2)}, {sreg(S_VC2)}")
+        I(f"s_mul_hi_i32 {sreg(S_T1)}, {sreg(S_T2)}, {sreg(S_VC2)}")
+        I(f"s_sub_u32 {sreg(58)}, {sreg(n0)}, {sreg(S_VCOL0)}")
+        I(f"s_lshl_b32 {sreg(58)}, {sreg(58)}, 1")
+        I(f"s_add_u32 {sreg(S_T0)}, {sreg(S_T0)}, {sreg(58)}")
+        I(f"s_addc_u32 {sreg(S_T1)}, {sreg(S_T1)}, 0")
+        add64(g, S_Y, S_VOUT, S_T0, S_T1)
+    g.L(lab)
+
+
+def generate(WN: int, epi: int, prefix: str, i8: bool = False, persistent: bool = False) -> str:
     """Issue order of the staging (one in-order vmcnt queue per wave): W(j) in half-step 2 j - 5, X(j) in half-step 2 j - 4, so at
     the END of the even half-step 2 s the wave has issued ... W(s+1) X(s+1) W(s+2) X(s+2): `s_waitcnt vmcnt(npw + 8)` there = the
     next K-step's operands have landed.  The one barrier per K-step stands right behind that wait: it makes W(s+1) visible (first
@@ -185,17 +315,28 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
     half-step of K-step s and refilled (X(s+3)) in the even half-step after it -- the reads are retired by the fragment waits of
     the W reads issued after them (LDS returns in order)."""
     c = Cfg(WN, epi, i8)
+    assert not (persistent and (i8 or epi in (EPI_PARTIAL, EPI_BIAS_SSQ)))
     g = Gen()
     I = g.I
     T = 128                                            # setup scratch (below the address registers, inside the fragment file)
     npw = c.npw
+    def ident():
+        I(f"v_and_b32 {vreg(c.V_LANE)}, 63, {vreg(V_TID)}")
+        I(f"v_lshrrev_b32 {vreg(T)}, 6, {vreg(V_TID)}")
+        I("s_nop 0")
+        I(f"v_readfirstlane_b32 {sreg(S_WAVE)}, {vreg(T)}")
+        I(f"v_and_b32 {vreg(c.V_R)}, 31, {vreg(c.V_LANE)}")
+        I(f"v_lshrrev_b32 {vreg(c.V_H)}, 5, {vreg(c.V_LANE)}")
+    if persistent:
+        ident()                                        # once: v0 (the workitem id) does not survive a tile; V_LANE / V_R / V_H / S_WAVE do
+        # ================= tile loop (persistent form): this tile's scalars =================
+        I(f"s_mov_b32 {sreg(S_PF)}, 0")
+        g.L(f"{prefix}_TILE")
+        gen_tile_map(g, S_TILE, T)
+        gen_tile_bases(g, c, S_X, S_W, S_ROWS, f"{prefix}_NEXT", True, prefix)
     # ================= setup =================
-    I(f"v_and_b32 {vreg(c.V_LANE)}, 63, {vreg(V_TID)}")
-    I(f"v_lshrrev_b32 {vreg(T)}, 6, {vreg(V_TID)}")
-    I("s_nop 0")
-    I(f"v_readfirstlane_b32 {sreg(S_WAVE)}, {vreg(T)}")
-    I(f"v_and_b32 {vreg(c.V_R)}, 31, {vreg(c.V_LANE)}")
-    I(f"v_lshrrev_b32 {vreg(c.V_H)}, 5, {vreg(c.V_LANE)}")
+    if not persistent:
+        ident()
     # descriptors: rows bound by num_records (rows past M / N read as zeros), the K offset travels in soffset
     for rs, base, rows, ld in ((S_XRS, S_X, S_ROWS, S_LDX), (S_WRS, S_W, S_COLS, S_LDW)):
         I(f"s_mov_b32 {sreg(rs)}, {sreg(base)}")
@@ -247,7 +388,10 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
     # prologue staging in the loop's own issue order: W(0) X(0) W(1) X(1) W(2)
     I(f"s_cmp_ge_u32 {sreg(S_T0)}, {sreg(S_ROWS)}")                        # idle waves (their 64 rows are all past M) stage W only
     I(f"s_cbranch_scc1 {prefix}_IDLE")
-    gen_epilogue_setup(g, c)                           # addresses, masks and the early reads of the epilogue (oldest in the queue)
+    n_early = gen_epilogue_setup(g, c)                 # addresses, masks and the early reads of the epilogue (oldest in the queue)
+    if persistent:                                     # this tile's first pieces were staged under the previous tile's epilogue
+        I(f"s_cmp_eq_u32 {sreg(S_PF)}, 1")
+        I(f"s_cbranch_scc1 {prefix}_STAGED")
     for j in range(NSLOT):
         for op in w_dma(c, j):
             I(op)
@@ -257,6 +401,18 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
     for r in range(c.nacc):                            # accumulators start from zero (while the first tiles fly)
         I(f"v_accvgpr_write_b32 {areg(r)}, 0")
     I(f"s_waitcnt vmcnt({2 * npw + 8})")               # W(0), X(0) have landed
+    if persistent:
+        I(f"s_branch {prefix}_READY")
+        g.L(f"{prefix}_STAGED")
+        # the source offsets advance as if the prologue had issued W(0..2), X(0..1) (the prefetch did, from the next-tile bases)
+        I(f"s_mov_b32 {sreg(S_WK)}, {128 * NSLOT}")
+        I(f"s_min_u32 {sreg(S_WK)}, {sreg(S_WK)}, {sreg(S_WKMAX)}")
+        I(f"s_mov_b32 {sreg(S_XK)}, {128 * XU}")
+        I(f"s_min_u32 {sreg(S_XK)}, {sreg(S_XK)}, {sreg(S_XKMAX)}")
+        for r in range(c.nacc):
+            I(f"v_accvgpr_write_b32 {areg(r)}, 0")
+        I(f"s_waitcnt vmcnt({n_early})")               # everything older than this tile's early reads: the staged pieces (and the last tile's stores)
+        g.L(f"{prefix}_READY")
     I("s_barrier")
     for op in x_frag_reads(c, 0) + w_frag_reads(c, 0):
         I(op)
@@ -296,17 +452,34 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
     if KN("NO_EPI"):
         I("s_waitcnt vmcnt(0)")
         I("s_endpgm")
+    if persistent:
+        gen_prefetch(g, c, prefix, "A")                # (older than every operation the epilogue issues: its counted waits are unaffected)
     tail_stores = gen_epilogue(g, c)
+    if persistent:
+        g.L(f"{prefix}_NEXT")                          # (also the target of a V tile that stores nothing)
+        I(f"s_add_u32 {sreg(S_TILE)}, {sreg(S_TILE)}, {sreg(S_GRID)}")
+        I(f"s_cmp_lt_u32 {sreg(S_TILE)}, {sreg(S_NTILES)}")
+        I(f"s_cbranch_scc1 {prefix}_TILE")
     # every load of the wave (the over-run staging pieces included: they are older) has landed once at most the epilogue's trailing
     # stores are outstanding; the wave does not wait for those to be acknowledged
-    I(f"s_waitcnt vmcnt({min(63, tail_stores)})")
+    I(f"s_waitcnt vmcnt({0 if persistent else min(63, tail_stores)})")
     I("s_endpgm")
     # ================= idle waves: their share of W, the barriers =================
     g.L(f"{prefix}_IDLE")
+    if persistent:
+        I(f"s_cmp_eq_u32 {sreg(S_PF)}, 1")
+        I(f"s_cbranch_scc1 {prefix}_IDLE_STAGED")
     for j in range(NSLOT):
         for op in w_dma(c, j):
             I(op)
     I(f"s_waitcnt vmcnt({2 * npw})")
+    if persistent:
+        I(f"s_branch {prefix}_IDLE_READY")
+        g.L(f"{prefix}_IDLE_STAGED")
+        I(f"s_mov_b32 {sreg(S_WK)}, {128 * NSLOT}")
+        I(f"s_min_u32 {sreg(S_WK)}, {sreg(S_WK)}, {sreg(S_WKMAX)}")
+        I("s_waitcnt vmcnt(0)")
+        g.L(f"{prefix}_IDLE_READY")
     I("s_barrier")
     I(f"s_mov_b32 {sreg(S_I)}, 0")
     g.L(f"{prefix}_IDLE_LOOP")
@@ -320,9 +493,58 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False) -> str:
         I(f"s_cbranch_scc1 {prefix}_IDLE_END")
     I(f"s_branch {prefix}_IDLE_LOOP")
     g.L(f"{prefix}_IDLE_END")
-    I("s_waitcnt vmcnt(0)")
-    I("s_endpgm")
+    if persistent:
+        gen_prefetch(g, c, prefix, "I")                # the barrier all waves share + this wave's share of the next tile's first pieces
+        I(f"s_branch {prefix}_NEXT")
+    else:
+        I("s_waitcnt vmcnt(0)")
+        I("s_endpgm")
     return finalize(g.out)
+
+
+def gen_prefetch(g: Gen, c: Cfg, prefix: str, tag: str):
+    """Persistent form, at the end of a tile's loop: one barrier (every wave is done reading the W slots), then the NEXT tile of this
+    workgroup is mapped and -- unless there is none, or it is a V tile that stores nothing -- its W(0..2) and, for waves that have
+    rows in it, X(0..1) are issued; S_PF says so to the next tile's prologue.  These operations are OLDER than anything the epilogue
+    issues, so its counted waits (which count younger operations) stand as they are."""
+    I = g.I
+    T = 128
+    npw = c.npw
+    I("s_barrier")
+    I(f"s_mov_b32 {sreg(S_PF)}, 0")
+    I(f"s_add_u32 {sreg(S_I)}, {sreg(S_TILE)}, {sreg(S_GRID)}")     # (the loop counter is dead here)
+    I(f"s_cmp_ge_u32 {sreg(S_I)}, {sreg(S_NTILES)}")
+    I(f"s_cbranch_scc1 {prefix}_PF_DONE_{tag}")
+    gen_tile_map(g, S_I, T)
+    gen_tile_bases(g, c, S_XN, S_WN, S_ROWSN, f"{prefix}_PF_DONE_{tag}", False, prefix)
+    I(f"s_mov_b32 {sreg(S_PF)}, 1")
+    # descriptors of the next tile (rows bound as in the setup), K offsets from zero
+    for rs, base, rows, ld in ((S_WRS, S_WN, None, S_LDW), (S_XRS, S_XN, S_ROWSN, S_LDX)):
+        I(f"s_mov_b32 {sreg(rs)}, {sreg(base)}")
+        I(f"s_and_b32 {sreg(rs + 1)}, {sreg(base + 1)}, 0xffff")
+        if rows is None:                               # N - n0 of the next tile, >= WN on this path: all WN rows of W are valid
+            I(f"s_mul_i32 {sreg(rs + 2)}, {sreg(ld)}, {c.WN}")
+        else:
+            I(f"s_min_u32 {sreg(S_T0)}, {sreg(rows)}, 256")
+            I(f"s_mul_i32 {sreg(rs + 2)}, {sreg(S_T0)}, {sreg(ld)}")
+        I(f"s_mov_b32 {sreg(rs + 3)}, 0x00020000")
+    I(f"s_mov_b32 {sreg(S_XK)}, 0")
+    I(f"s_mov_b32 {sreg(S_WK)}, 0")
+    I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_WAVE)}, 6")
+    I(f"s_cmp_ge_u32 {sreg(S_T0)}, {sreg(S_ROWSN)}")                # this wave has no rows in the next tile: W only
+    I(f"s_cbranch_scc1 {prefix}_PF_WONLY_{tag}")
+    for j in range(NSLOT):
+        for op in w_dma(c, j):
+            I(op)
+        if j < XU:
+            for op in x_dma(c, j):
+                I(op)
+    I(f"s_branch {prefix}_PF_DONE_{tag}")
+    g.L(f"{prefix}_PF_WONLY_{tag}")
+    for j in range(NSLOT):
+        for op in w_dma(c, j):
+            I(op)
+    g.L(f"{prefix}_PF_DONE_{tag}")
 
 
 
@@ -376,11 +598,13 @@ def gen_epilogue_setup(g: Gen, c: Cfg):
             I(f"v_lshlrev_b32 {vreg(T + 48)}, 2, {vreg(T + 48)}")
             I(f"global_load_dword {vreg(c.V_SX + 2 * mb)}, {vreg(T + 48)}, {sreg(S_SX, 2)}")
     # early reads
+    n0 = sum(1 for l in g.out if l.startswith("global_load"))
     for nb in range(c.early_nb):
         for g4 in range(4):
             I(f"global_load_dwordx2 {vreg(c.V_EB + 8 * nb + 2 * g4, 2)}, {vreg(EA + 2)}, {sreg(S_BIAS, 2)} offset:{64 * nb + 16 * g4}")
     if c.nl:
         epi_block_loads(g, c, 0, c.V_E0)
+    return sum(1 for l in g.out if l.startswith("global_load")) - n0 + (c.MB if c.i8 else 0)      # vector-memory reads issued here
 
 
 def epi_block_loads(g: Gen, c: Cfg, j: int, P: int):
@@ -589,7 +813,8 @@ if __name__ == "__main__":
         sys.argv.remove("--diag")                                            # (attn_asm_gen saw it at import: timing-only knobs allowed)
     WN, epi = int(sys.argv[1]), int(sys.argv[2])
     i8 = len(sys.argv) > 5 and sys.argv[5] == "i8"
-    txt = generate(WN, epi, f"GA{WN}E{epi}" + ("I8" if i8 else ""), i8)
+    pers = len(sys.argv) > 5 and sys.argv[5] == "p"
+    txt = generate(WN, epi, f"GA{WN}E{epi}" + ("I8" if i8 else "") + ("P" if pers else ""), i8, pers)
     probs = lint(txt)
     for p in probs[:20]:
         print("LINT:", p, file=sys.stderr)

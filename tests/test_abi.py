@@ -116,9 +116,9 @@ def test_gemm_plan_names_the_kernel_family_a_call_takes():
         assert lib.ll_set_tuning(b"gemm_asm", 0) == 0
         assert plan(L, F1, Cw, 0, 1, 1).startswith("gemm_kernel_v5")
     finally:
-        assert lib.ll_set_tuning(b"gemm_asm", 3) == 0
+        assert lib.ll_set_tuning(b"gemm_asm", 35) == 0
     for key in (b"attn_asm", b"attn_asm_min_keys", b"gemm_asm"):
-        assert lib.ll_set_tuning(key, {b"attn_asm": 1, b"attn_asm_min_keys": 512, b"gemm_asm": 3}[key]) == 0, key
+        assert lib.ll_set_tuning(key, {b"attn_asm": 1, b"attn_asm_min_keys": 512, b"gemm_asm": 35}[key]) == 0, key
     for gone in (b"no_such_key", b"attn_mfma16", b"attn_sk_wgs", b"gemm_ws", b"gemm_splitk_l2"):      # pruned in round 4: experiments/
         assert lib.ll_set_tuning(gone, 1) == -1, gone
 

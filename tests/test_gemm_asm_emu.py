@@ -264,3 +264,103 @@ def test_gemm_asm_text_assembles(tmp_path):
         r = subprocess.run([clang, "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", str(src), "-o", str(tmp_path / "k.o")],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[:2000]
+
+
+# ---- persistent form: a workgroup walks several tiles and stages the next tile's first pieces under the current epilogue ---------
+def run_persistent(WN, epi, mode, M=600, ntn=2, K=448, grid=2, gm=2, seed=0, frame_len=130, vcache=None):
+    """The whole launch, one emulated workgroup after the other over shared memory: Y[M, ntn * WN] = epilogue(X W^T + b).  vcache =
+    (S, v_lo, v_hi, v_shift): the last third of the columns is the V third of a fused QKV projection, redirected into cache_v [S, C]."""
+    rng = np.random.default_rng(seed)
+    text = G.generate(WN, epi, f"P{WN}E{epi}", False, True)
+    assert G.lint(text) == []
+    N = ntn * WN
+    ntm = (M + 255) // 256
+    x = bf(rng.standard_normal((M, K)))
+    w = bf(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = bf(0.1 * rng.standard_normal(N))
+    res = bf(rng.standard_normal((M, N)))
+    nframes = (M - 1) // frame_len + 1
+    gate = bf(0.5 * rng.standard_normal((nframes, N)))
+    mem = E.Memory()
+    ax, aw, ab, ar, ag = mem.alloc(x), mem.alloc(w), mem.alloc(bias), mem.alloc(res), mem.alloc(gate)
+    ay = mem.alloc(np.full((M, N), 0x7FC0, dtype=np.uint16))
+    av = 0
+    if vcache is not None:
+        S, v_lo, v_hi, v_shift = vcache
+        C = N // 3
+        av = mem.alloc(np.full((S, C), 0x7FC0, dtype=np.uint16))
+    ntiles = ntm * ntn
+    for wg in range(min(grid, ntiles)):
+        m = E.Machine(text, mem, 4, mode=mode, lds_bytes=G.Cfg(WN, epi).lds_bytes)
+        for wv in m.waves:
+            s = wv.s
+            def put64(i, val):
+                s[i], s[i + 1] = val & 0xFFFFFFFF, val >> 32
+            put64(G.S_XB, ax); put64(G.S_WB, aw); put64(G.S_YB, ay); put64(G.S_BIASB, ab); put64(G.S_RESB, ar); put64(G.S_GATEB, ag)
+            s[G.S_LDX], s[G.S_LDW], s[G.S_LDO0] = K * 2, K * 2, N * 2
+            s[G.S_MM], s[G.S_NN], s[G.S_NK] = M, N, K // 64
+            s[G.S_FLEN], s[G.S_GSTRIDE] = frame_len, N * 2
+            s[G.S_TILE], s[G.S_GRID], s[G.S_NTILES], s[G.S_NTM], s[G.S_NTN], s[G.S_GM] = wg, min(grid, ntiles), ntiles, ntm, ntn, gm
+            put64(G.S_VOUT, av)
+            if vcache is not None:
+                s[G.S_VCOL0], s[G.S_VC2], s[G.S_VSHIFT], s[G.S_VLO], s[G.S_VHI] = 2 * C, C * 2, v_shift & 0xFFFFFFFF, v_lo, v_hi
+            wv.v[G.V_TID] = 64 * wv.id + np.arange(64, dtype=np.uint32)
+            wv.v[1:] = 0x7FC0BEEF
+            wv.a[:] = 0x7FC0BEEF
+        m.run()
+    acc = (f32(x).astype(np.float64) @ f32(w).astype(np.float64).T).astype(np.float32)
+    v = rbf(acc + f32(bias)[None, :])
+    if epi == G.EPI_BIAS:
+        want = v
+    elif epi == G.EPI_GELU:
+        xx = v.astype(np.float32)
+        k0, k1, ce = np.float32(0.7978845608028654), np.float32(0.044715), np.float32(-2.0 * 1.4426950408889634)
+        u = k0 * (xx + ((k1 * xx) * xx) * xx)
+        e = np.exp2((ce * u).astype(np.float64)).astype(np.float32)
+        want = rbf(xx * (np.float32(1.0) / (np.float32(1.0) + e)))
+    elif epi == G.EPI_RES:
+        want = rbf(f32(res) + v)
+    else:
+        want = rbf(f32(res) + rbf(v * f32(gate)[np.arange(M) // frame_len]))
+    yraw = mem.get(ay).view(np.uint16).reshape(M, N)
+    got = f32(yraw).astype(np.float64)
+    cache = None if vcache is None else mem.get(av).view(np.uint16).reshape(vcache[0], N // 3)
+    return got, want.astype(np.float64), yraw, cache
+
+
+@pytest.mark.parametrize("WN,epi,mode,grid,gm", [(224, G.EPI_GELU, "lazy", 2, 2), (128, G.EPI_GATE_RES, "mixed", 4, 4), (192, G.EPI_BIAS, "eager", 3, 1),
+                                                 (128, G.EPI_RES, "lazy", 8, 4)])
+def test_gemm_asm_persistent_walks_every_tile(WN, epi, mode, grid, gm):
+    """generate(persistent=True): workgroup w computes tiles w, w + grid, ... of the launch (the tile -> (m-tile, n-tile) map of
+    gemm_common.h evaluated in the kernel), staging the next tile's W(0..2) / X(0..1) before the current epilogue.  Every element of
+    Y is written exactly once with the classic kernel's arithmetic: ragged last m-tile (88 rows: waves that are idle in one tile
+    and active in the next), more tiles than workgroups, a workgroup count that does not divide them."""
+    got, want, yraw, _ = run_persistent(WN, epi, mode, M=600, ntn=2, K=448, grid=grid, gm=gm)
+    assert not (yraw == 0x7FC0).all(axis=1).any(), "a tile was never written"
+    assert np.isfinite(got).all()
+    assert (got == want).mean() > 0.96 and np.abs(got - want).max() < 0.08, ((got == want).mean(), np.abs(got - want).max())
+
+
+def test_gemm_asm_persistent_equals_the_classic_kernel_bit_for_bit():
+    """Same tile, same K order, same epilogue text: the persistent form's output bits are the classic form's."""
+    got_p, _, _, _ = run_persistent(128, G.EPI_GATE_RES, "lazy", M=256, ntn=1, K=448, grid=1, gm=1, seed=7, frame_len=130)
+    rng_case = run_case(128, G.EPI_GATE_RES, "lazy", rows_valid=256, K=448, seed=7, m0=0, frame_len=130)
+    assert np.array_equal(got_p, rng_case[0])
+
+
+@pytest.mark.parametrize("v_lo,v_hi,grid", [(100, 560, 2), (300, 600, 5), (0, 200, 3)])
+def test_gemm_asm_persistent_qkv_v_redirect(v_lo, v_hi, grid):
+    """The fused QKV projection on the persistent 192-wide kernel: tiles of the V third (columns >= 2 C) store token t into cache row
+    t + v_shift for v_lo <= t < v_hi only -- per-tile base, row stride and row window computed in the kernel; V tiles with nothing
+    to store are skipped (and never prefetched)."""
+    M, C, S, v_shift = 600, 192, 900, 250
+    got, want, yraw, cache = run_persistent(192, G.EPI_BIAS, "lazy", M=M, ntn=3, K=320, grid=grid, gm=2, seed=3, vcache=(S, v_lo, v_hi, v_shift))
+    qk = slice(0, 2 * C)
+    assert (got[:, qk] == want[:, qk]).mean() > 0.97 and np.abs(got[:, qk] - want[:, qk]).max() < 0.05
+    assert (yraw[:, 2 * C:] == 0x7FC0).all(), "the V third of Y must stay unwritten"
+    cv = f32(cache).astype(np.float64)
+    hi = min(M, v_hi)
+    rows = np.arange(v_lo, hi) + v_shift
+    assert (cv[rows] == want[v_lo:hi, 2 * C:]).mean() > 0.97 and np.abs(cv[rows] - want[v_lo:hi, 2 * C:]).max() < 0.05
+    other = np.ones(S, dtype=bool); other[rows] = False
+    assert (cache[other] == 0x7FC0).all(), "cache rows outside the insert window were written"

@@ -421,7 +421,7 @@ def test_qkv_projection_with_v_insert_is_bit_identical(ops, B, F, hp, wp, H, K, 
             mask = torch.ones(S, dtype=torch.bool); mask[ws:ws + wl] = False
             assert torch.equal(bq[2][:, mask], cv0[:, mask])
     finally:
-        _set_tuning("gemm_asm", 3)
+        _set_tuning("gemm_asm", 35)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(4680, 8960, 1536, "gelu"), (4680, 1536, 1536, "gate"), (4680, 1536, 1536, "res"),
@@ -452,7 +452,7 @@ def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
         assert b"gemm_kernel_v" in buf.value, buf.value
         want = ops.gemm(x, w, b, code, **kw)
     finally:
-        _set_tuning("gemm_asm", 3)
+        _set_tuning("gemm_asm", 35)
     got = ops.gemm(x, w, b, code, **kw)
     again = ops.gemm(x, w, b, code, **kw)
     assert torch.equal(got, again)
@@ -462,6 +462,70 @@ def test_gemm_asm_kernels_match_hip_kernels(ops, M, N, K, epi):
         ref = (x.double() @ w.double().t() + b.double()).cpu()
         if epi == "bias":
             assert rel_l2(got.cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4680, 8960, 1536, "gelu"),      # FFN1: 760 tiles on 256 CUs, 2.97 rounds
+                                       (18720, 1536, 1536, "gate"),     # the recache forward's O projection: 888 tiles
+                                       (18720, 1536, 8960, "gate"),     # ... FFN2
+                                       (18720, 1536, 1536, "res"), (18720, 1536, 1536, "bias"),
+                                       (9360, 8960, 1536, "gelu"),      # B = 2
+                                       (2100, 3584, 256, "gelu")])      # ragged last m-tile (52 rows), shortest K (4 K-steps), 9 x 16 = 144 tiles: classic
+def test_gemm_asm_persistent_form_is_the_classic_form_bit_for_bit(ops, M, N, K, epi):
+    """Launches with more tiles than CUs run the PERSISTENT generated kernels (gemm_asmp_*: one workgroup per CU walks its tiles and
+    stages the next tile's first pieces under the current epilogue; tuning key gemm_asm bit 5).  Same tiles, same K order, same
+    epilogue text: the output must equal the classic one-tile-per-workgroup kernels' bit for bit."""
+    x = hn("px2", (M, K), device=DEV)
+    w = (hn("pw2", (N, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("pb2", (N,), 0.1, device=DEV)
+    kw = {}
+    code = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_BIAS_GELU, "gate": ops.EPI_BIAS_GATE_RES, "res": ops.EPI_BIAS_RES}[epi]
+    if epi in ("gate", "res"):
+        kw["res"] = hn("pr2", (M, N), device=DEV)
+    if epi == "gate":
+        kw.update(e=hn("pe2", (1, 3, 6, N), 0.5, device=DEV), mod=None, gate_idx=2, rows_per_batch=M, frame_len=M // 3)
+    from longlive_amd import _lib
+    import ctypes as C
+    buf = C.create_string_buffer(320)
+    _lib.check(_lib.load().ll_gemm_plan_epi(M, N, K, 0, code, 1, buf, 320), "plan")
+    tiles = ((M + 255) // 256) * (N // (224 if epi == "gelu" else 128))
+    assert (b"gemm_asmp_" in buf.value) == (tiles > 256), buf.value
+    got = ops.gemm(x, w, b, code, **kw)
+    again = ops.gemm(x, w, b, code, **kw)
+    try:
+        _set_tuning("gemm_asm", 3)
+        _lib.check(_lib.load().ll_gemm_plan_epi(M, N, K, 0, code, 1, buf, 320), "plan")
+        assert b"gemm_asm_" in buf.value, buf.value
+        want = ops.gemm(x, w, b, code, **kw)
+    finally:
+        _set_tuning("gemm_asm", 35)
+    assert torch.equal(got, again) and torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+
+
+@pytest.mark.parametrize("B,L,ws,ro,wl", [(1, 4680, 14040, 0, 4680), (1, 4680, 4680, 3000, 1680), (1, 18720, 0, 0, 18720), (1, 4680, 4680, 4680, 0)])
+def test_qkv_persistent_form_is_the_classic_form_bit_for_bit(ops, B, L, ws, ro, wl):
+    """The fused QKV projection (V third redirected into the KV cache) on the persistent 192-wide kernel against the classic one: the
+    q | k thirds and the whole cache, bit for bit -- steady state, a partial insert window, the recache forward (L = 18720) and a
+    pass that inserts nothing (every V tile skipped)."""
+    C, K, S = 1536, 1536, 18720
+    x = hn("qx2", (B, L, K), device=DEV)
+    w = (hn("qw2", (3 * C, K), device=DEV) / math.sqrt(K)).to(bf)
+    b = hn("qb2", (3 * C,), 0.1, device=DEV)
+    cv0 = hn("qc2", (B, S, 12, 128), device=DEV)
+
+    def run():
+        cv = cv0.clone()
+        out = ops.gemm_qkv_v_insert(x, w, b, cv, ws, ro, wl)
+        return out[..., :2 * C].clone(), cv
+
+    got = run()
+    try:
+        _set_tuning("gemm_asm", 3)
+        want = run()
+    finally:
+        _set_tuning("gemm_asm", 35)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    if wl == 0:
+        assert torch.equal(got[1], cv0)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(512, 4096, 4096, "res"), (512, 8192, 4096, "bias"), (4096, 512, 4096, "bias"),
@@ -487,7 +551,7 @@ def test_gemm_small_m_split_k_matches_plain(ops, M, N, K, epi):
         assert lib.ll_gemm_ksplit_plan(M, N, K) == 0
         want = ops.gemm(x, w, b, code, **kw)
     finally:
-        _set_tuning("gemm_asm", 3)
+        _set_tuning("gemm_asm", 35)
     assert_bf16_close(got, want, 2, 0.97, f"small-M split-K {M}x{N}x{K} {epi}", atol=4e-2 if epi == "res" else None)
     ref = (x.double() @ w.double().t() + b.double()).cpu()
     if epi == "bias":
@@ -550,7 +614,7 @@ def test_gemm_asm_w8a8_equals_the_hip_w8a8_kernels(ops, M, N, K, epi):
         got = ops.gemm_w8a8(xq, sx, wq, sw, b, code, **kw)
         again = ops.gemm_w8a8(xq, sx, wq, sw, b, code, **kw)
     finally:
-        _set_tuning("gemm_asm", 3)
+        _set_tuning("gemm_asm", 35)
     assert torch.equal(got, again)
     if epi == "gelu":
         assert_bf16_close(got, want, 1, 0.995, f"w8a8 asm {M}x{N}x{K} {epi}")

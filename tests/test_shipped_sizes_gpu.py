@@ -231,7 +231,7 @@ def test_real_shape_block_vs_reference(kernels):
     try:
         _real_shape_block(kernels)
     finally:
-        _tuning("gemm_asm", 3); _tuning("attn_asm", 1)
+        _tuning("gemm_asm", 35); _tuning("attn_asm", 1)
 
 
 def _real_shape_block(kernels):

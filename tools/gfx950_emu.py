@@ -396,6 +396,8 @@ class Machine:
 
     def i_s_mul_i32(self, w, i): self._sarith(w, i, lambda a, b: a * b, signed=True)
     def i_s_mul_hi_u32(self, w, i): self._sarith(w, i, lambda a, b: (a * b) >> 32)
+    def i_s_mul_hi_i32(self, w, i): self._sarith(w, i, lambda a, b: (a * b) >> 32, signed=True)
+    def i_s_cmp_le_u32(self, w, i): w.scc = int(self.rs(w, i.ops[0]) <= self.rs(w, i.ops[1]))
 
     def i_s_lshl_b32(self, w, i):
         a, b, r = self._sarith(w, i, lambda a, b: a << (b & 31))
