@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | seqtrace=<env> | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
+#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -87,6 +87,12 @@ for r in rows[:14]:
     print("  %-64.64s calls %5s avg %9.1f us  total %8.1f ms" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
       rm -f $O/seqtrace_$tag/*/*kernel_trace.csv $O/seqtrace_$tag/*/*.db ;;
+    abenv)         # interleaved A/B of the layer sequence under kbench environment switches: abenv=<ENV=..>[/rounds]  (timing-only experiments)
+      v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=3; rc=0
+      for i in $(seq 1 $n); do
+        echo -n "[shipped] "; timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
+        echo -n "[$v] "; env $v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
+      done | tee -a $O/abenv.txt ;;
     ablib)         # interleaved A/B of the layer sequence: in-tree library vs a variant built by tools/build_variant.sh (ablib=<name>[/rounds])
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=3; rc=0
       for i in $(seq 1 $n); do

@@ -320,6 +320,49 @@ static void bench_layerseq(int layers) {
     if (ON(12)) LL(ll_gemm_bf16(ffh.d, w2.d, b2.d, xs.d, L, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 5, L, FS, s));
   };
 #undef ON
+  // KB_SPLIT=<rows> (TIMING-ONLY): the layer as TWO row ranges [0, rows) / [rows, L) on two HIP streams that meet only at the
+  // self-attention (each half's attention reads the K / V both halves inserted) -- would a token split of ONE prompt stream let one
+  // half's row kernels / epilogues overlap the other half's dense kernels?  (frame indices are not kept: results invalid)
+  if (const char* sp = getenv("KB_SPLIT")) {
+    const int R0 = atoi(sp);
+    hipStream_t st[2]; CK(hipStreamCreate(&st[0])); CK(hipStreamCreate(&st[1]));
+    hipEvent_t ev[2]; CK(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    auto half = [&](int hf, int phase) {
+      hipStream_t t = st[hf];
+      const int r0 = hf ? R0 : 0, M = hf ? L - R0 : R0, fl = M / 2;
+      uint16_t *x_ = xs.d + (size_t)r0 * C, *h_ = h.d + (size_t)r0 * C, *qkv_ = qkv.d + (size_t)r0 * 3 * C, *q_ = q.d + (size_t)r0 * C, *att_ = att.d + (size_t)r0 * C;
+      uint16_t* ffh_ = ffh.d + (size_t)r0 * F1;
+      if (phase == 0) {
+        LL(ll_ln_modulate(x_, h_, e.d, nullptr, 6, 0, 1, 1, M, C, 1, 1e-6f, t));
+        LL(ll_gemm_bf16_qkv(h_, wqkv.d, bqkv.d, qkv_, M, 3 * C, C, C, 3 * C, vc.d, 1, M, S, S - L + r0, 0, M, t));
+        LL(ll_qk_norm_rope_kv_store(qkv_, nw.d, nw.d, rf, rhw, q_, kc.d, nullptr, 1, M, C, 128, fl, 12, S, S - L + r0, 0, M, 1e-6f, t));
+        CK(hipEventRecord(ev[hf], t));
+        return;
+      }
+      CK(hipStreamWaitEvent(t, ev[1 - hf], 0));
+      LL(ll_flash_attn(q_, kc.d, vc.d, att_, 1, M, H, C, C, C, (long long)S * C, 0, S, 0, 0, scale, t));
+      LL(ll_gemm_bf16(att_, wo.d, bo.d, x_, M, C, C, C, C, LL_EPI_BIAS_GATE_RES, x_, e.d, nullptr, 6, 2, M, M, t));
+      LL(ll_layernorm_affine(x_, nw.d, nb.d, h_, M, C, 1e-6f, t));
+      LL(ll_gemm_bf16_ssq(h_, wcq.d, bo.d, q_, ssq + r0, M, C, C, C, C, t));      // (plane stride M here: timing only)
+      LL(ll_flash_attn_qnorm(q_, ssq + r0, nw.d, 1e-6f, ck.d, cv.d, att_, 1, M, H, C, C, C, (long long)512 * C, 0, 512, scale, t));
+      LL(ll_gemm_bf16(att_, wco.d, bo.d, x_, M, C, C, C, C, LL_EPI_BIAS_RES, x_, nullptr, nullptr, 0, 0, 0, 0, t));
+      LL(ll_ln_modulate(x_, h_, e.d, nullptr, 6, 3, 4, 1, M, C, 1, 1e-6f, t));
+      LL(ll_gemm_bf16(h_, w1.d, b1.d, ffh_, M, F1, C, C, F1, LL_EPI_BIAS_GELU, nullptr, nullptr, nullptr, 0, 0, 0, 0, t));
+      LL(ll_gemm_bf16(ffh_, w2.d, b2.d, x_, M, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, x_, e.d, nullptr, 6, 5, M, M, t));
+    };
+    auto layer2 = [&]() { half(0, 0); half(1, 0); half(0, 1); half(1, 1); };
+    for (int i = 0; i < 3; ++i) layer2();
+    CK(hipDeviceSynchronize());
+    hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+    CK(hipEventRecord(t0, st[0])); CK(hipStreamWaitEvent(st[1], t0, 0));
+    for (int i = 0; i < layers; ++i) layer2();
+    CK(hipEventRecord(ev[1], st[1])); CK(hipStreamWaitEvent(st[0], ev[1], 0));
+    CK(hipEventRecord(t1, st[0])); CK(hipEventSynchronize(t1));
+    float ms2; CK(hipEventElapsedTime(&ms2, t0, t1));
+    printf("layerseq: TIMING-ONLY token split %d + %d rows on two streams: %d layers, %.1f us per layer\n", R0, L - R0, layers, ms2 * 1e3 / layers);
+    hipFree(rf); hipFree(rhw); hipFree(ssq);
+    return;
+  }
   for (int i = 0; i < 3; ++i) layer();
   CK(hipStreamSynchronize(s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
