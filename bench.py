@@ -634,14 +634,15 @@ def run_replica(args, rank, world, local_rank, sync):
         achieved = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
         traffic, src = None, None
         plan_now = _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1)
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_inpipe.json")   # counters of the SAME kernel in the pipeline's launch order
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_inpipe.json")   # counters of the SAME kernel in the pipeline's launch order
         if os.path.exists(pmc) and "flash_attn_asm_kernel" in plan_now:
             try:
-                row = [k for k in json.load(open(pmc))["kernels"] if "flash_attn_asm_kernel" in k["kernel"]][0]
+                row = [k for k in json.load(open(pmc))["kernels"] if "flash_attn_asm_kernel" in k["kernel"] and "Lk=512" not in k["kernel"]][0]
                 traffic = row["fabric_bytes_per_launch"]
-                src = ("profiles/r03_pmc_inpipe.json: rocprofv3 --pmc passes over tools/kbench layerseq (the layer's 13 launches in "
-                       "model order) on this kernel and shape (TCC_EA0_RDREQ / _32B / TCC_BUBBLE, TCC_EA0_WRREQ / _64B; gfx950 x2 read "
-                       "correction); NOT measured in this run (rocprofv3 --pmc over a torch process segfaults here)")
+                src = ("profiles/r04_pmc_inpipe.json: rocprofv3 --pmc passes (separate TCC read / write passes) over tools/kbench layerseq -- "
+                       "the layer's 12 launches in model order -- on this kernel and shape (TCC_EA0_RDREQ / _32B / TCC_BUBBLE, "
+                       "TCC_EA0_WRREQ / _64B; gfx950 x2 read correction); a committed figure, NOT collected in this run (counters need "
+                       "their own profiled passes: tools/gpu_batch.sh pmc_inpipe; MFMA utilisation over bench.py itself: pmc_bench)")
             except Exception:
                 traffic = None
         res["roofline"] = {"bound": "mfma", "kernel": plan_now + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,

@@ -30,11 +30,7 @@
 #define V2_BM 256
 #define V2_STAGE ((V2_BM + BN) * ROWB)   // 48 KiB
 
-// STAG: waves 4-7 (the SIMD partners of waves 0-3) run HALF A K-STEP behind: they defer the 16 MFMAs of a tile's second k-half
-// to the start of the next iteration, their fragments waiting in registers across the barrier.  At every barrier release one
-// wave of each SIMD then has matrix work ready while its partner starts with LDS reads, instead of both waiting for reads and
-// then contending for the pipe (MI355X_MICROARCH.md, "two waves that run the same program with one barrier per block").
-template <int EPI, bool I8, bool STAG>
+template <int EPI, bool I8>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict__ X, const char* __restrict__ Wt,
                                                          bf16* __restrict__ Y, int M, int N, int nk, size_t xrow_bytes,
                                                          size_t wrow_bytes, int ldo, int ntm, int ntn, int gm, int lds_epi, EpiArgs ea) {
@@ -63,7 +59,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
 
   const int fr = lane & 15, fg = lane >> 4;
   const bool live = m0 + wm * 64 < M;       // wave-uniform
-  const bool late = STAG && wave >= 4;      // wave-uniform
   int slot = 0;
 #define V2_READ(WF, XF, KS)                                                                      \
   _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                \
@@ -76,49 +71,30 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v2(const char* __restrict_
 #define V2_MMA(WF, XF)                                                                           \
   _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                  \
   _Pragma("unroll") for (int b = 0; b < 4; ++b) acc[a][b] = Ty<I8>::mma(WF[a], XF[b], acc[a][b]);
-  frag_t wd[4], xd[4];                      // STAG: the second k-half's fragments (consumed one barrier later by the late group)
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed; tile kt+1 may be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (STAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the deferred fragments have left the slot restaged below
     __builtin_amdgcn_s_barrier();      // every wave's share of tile kt is in LDS; slot (kt+2)%3 is no longer being read
     const bool do_stage = kt + 2 < nk && !(lds_epi & 0x100);          // (0x100: timing experiment, results invalid)
     int s2 = slot + 2;
     s2 = s2 >= 3 ? s2 - 3 : s2;
-    if (do_stage && !late) stage(kt + 2, s2);          // STAG: the late group issues its share mid-iteration (below), so that
-                                                        // the two waves of a SIMD are never both busy issuing LDS-DMA pieces
+    if (do_stage) stage(kt + 2, s2);
     const char* xs = smem + slot * V2_STAGE;
     const char* ws = xs + V2_BM * ROWB;
-    if (!live || (lds_epi & 0x200)) {   // rows past M (last m-tile): stage and sync only -- the chip runs at its power cap,
-      if (do_stage && late) stage(kt + 2, s2);                  // idle matrix pipes are speed elsewhere
+    if (!live || (lds_epi & 0x200)) {   // rows past M (last m-tile): stage and sync only (idle matrix pipes are speed elsewhere)
       slot = slot == 2 ? 0 : slot + 1;
       continue;
     }
     __builtin_amdgcn_s_setprio(1);
-    if (STAG) {
-      if (late && kt > 0) { V2_MMA(wd, xd); }
-      frag_t wf[4], xf[4];
-      V2_READ(wf, xf, 0);
-      V2_MMA(wf, xf);
-      if (late) {
-        __builtin_amdgcn_s_setprio(0);
-        if (do_stage) stage(kt + 2, s2);
-        __builtin_amdgcn_s_setprio(1);
-      }
-      V2_READ(wd, xd, 1);
-      if (!late) { V2_MMA(wd, xd); }
-    } else {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        frag_t wf[4], xf[4];
-        V2_READ(wf, xf, ks);
-        V2_MMA(wf, xf);
-      }
+    for (int ks = 0; ks < 2; ++ks) {
+      frag_t wf[4], xf[4];
+      V2_READ(wf, xf, ks);
+      V2_MMA(wf, xf);
     }
     __builtin_amdgcn_s_setprio(0);
     slot = slot == 2 ? 0 : slot + 1;
   }
-  if (STAG && late && live && nk > 0) { V2_MMA(wd, xd); }
 #undef V2_READ
 #undef V2_MMA
   if (lds_epi) {
@@ -489,8 +465,8 @@ static int launch_gemm(const void* x, const void* w, bf16* out, int M, int N, in
       hipLaunchKernelGGL((gemm_kernel_v3<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk,   \
                          xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                      \
     } else {                                                                                                           \
-      (void)ll_lds_attr((const void*)gemm_kernel_v2<E, I8, false>, (int)lds);                                          \
-      hipLaunchKernelGGL((gemm_kernel_v2<E, I8, false>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
+      (void)ll_lds_attr((const void*)gemm_kernel_v2<E, I8>, (int)lds);                                          \
+      hipLaunchKernelGGL((gemm_kernel_v2<E, I8>), grid, block, lds, s, (const char*)x, (const char*)w, out, M, N, nk, \
                          xrow_bytes, wrow_bytes, ldo, ntm, ntn, gm, lds_epi, ea);                                      \
     }                                                                                                                  \
   } while (0)

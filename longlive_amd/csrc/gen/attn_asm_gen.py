@@ -113,6 +113,9 @@ def knobs_header(path):
 
 
 LSUM = KNOB("LSUM", 0)                       # 1: row sums by the matrix pipe (ones-MFMA into LACC); 0: by v_add_f32 into 4 partials per q-block
+DOT_LSUM = KNOB("DOT_LSUM", 0)               # LSUM = 0: row sums by v_dot2c_f32_bf16 (l += P.lo * 1 + P.hi * 1) on the PACKED bf16 P registers: 32 per tile
+                                             # instead of 64 v_add_f32, four accumulators per q-block as before; sums what P.V multiplies
+S_ONES = 46                                  # (1.0, 1.0) in bf16 for DOT_LSUM
 PK_LSUM = KNOB("PK_LSUM", 0)                 # LSUM = 0: row sums by v_pk_add_f32 on element pairs (two pair-accumulators per q-block) instead of v_add_f32 per element
 ADD_LATE = KNOB("ADD_LATE", 0)               # LSUM = 0: the adds of the elements whose registers survive the in-place pack (registers
                                              # 8..15 of every score tile) are issued in phase B instead of phase A
@@ -258,7 +261,9 @@ def finish_ops(y, with_pos=False):
     for t in range(n + DC + 2):
         if t < n:
             ops.append((t, (f"v_mov_b32 {vreg(elems[t][1])}, {vreg(elems[t][1])}" if noexp else f"v_exp_f32 {vreg(elems[t][1])}, {vreg(elems[t][1])}")))
-        if not LSUM and 2 <= t < n + 2:
+        if not LSUM and DOT_LSUM:
+            pass                                          # (the sums ride on the packed registers: below, one slot after each cvt_pk)
+        elif not LSUM and 2 <= t < n + 2:
             qb, r, _, j = elems[t - 2]
             late = ADD_LATE and (r & 15) >= 8
             if PK_LSUM:                                   # one packed add per PAIR of elements (after the second one's exp): 32 instead of 64 per tile
@@ -270,6 +275,9 @@ def finish_ops(y, with_pos=False):
         if t >= DC and (t - DC) % 2 == 0 and t - DC < n:
             qb, r0, dst, j = elems[t - DC]
             ops.append((t, f"v_cvt_pk_bf16_f32 {vreg(dst)}, {vreg(r0)}, {vreg(r0 + 1)}"))
+        if DOT_LSUM and not LSUM and t >= DC + 1 and (t - DC - 1) % 2 == 0 and t - DC - 1 < n:
+            qb, r0, dst, j = elems[t - DC - 1]
+            ops.append((t, f"v_dot2c_f32_bf16 {vreg(V_L + 4 * qb + ((j >> 1) & 3))}, {sreg(S_ONES)}, {vreg(dst)}"))
     if KNOB("NO_FIN", 0):
         ops = []
     return ops if with_pos else [o for _, o in ops]
@@ -420,6 +428,8 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
     I(f"v_and_b32 {vreg(V_R)}, 31, {vreg(V_LANE)}")
     I(f"v_lshrrev_b32 {vreg(V_H)}, 5, {vreg(V_LANE)}")
     I(f"s_mov_b32 {sreg(S_THR)}, {hex(f32bits(THR))}")
+    if DOT_LSUM:
+        I(f"s_mov_b32 {sreg(S_ONES)}, 0x3f803f80")
     I(f"s_mov_b32 {sreg(S_NINF)}, 0xff800000")
     I(f"s_lshl_b32 {sreg(S_STEP)}, {sreg(S_LDK)}, 6")                       # bytes per 64-key tile
     I(f"s_sub_u32 {sreg(S_MASKI)}, {sreg(S_NT)}, 1")

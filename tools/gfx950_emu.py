@@ -565,6 +565,14 @@ class Machine:
         self.wv(w, d, f2u(lo.astype(np.float32)), 0)
         self.wv(w, d, f2u(hi.astype(np.float32)), 1)
 
+    def i_v_dot2c_f32_bf16(self, w, i):
+        d, a, b = i.ops
+        A, B, D = self.rv(w, a), self.rv(w, b), u2f(self.rv(w, d)).astype(np.float64)
+        lo = bf16_to_f32(A & U32(0xFFFF)).astype(np.float64) * bf16_to_f32(B & U32(0xFFFF)).astype(np.float64)
+        hi = bf16_to_f32(A >> U32(16)).astype(np.float64) * bf16_to_f32(B >> U32(16)).astype(np.float64)
+        with np.errstate(all="ignore"):
+            self.wv(w, d, f2u((lo + hi + D).astype(np.float32)))
+
     def i_v_cvt_f32_u32(self, w, i): self._valu(w, i, lambda a: f2u(a.astype(np.float32)), 1)
     def i_v_cvt_f32_i32(self, w, i): self._valu(w, i, lambda a: f2u(a.view(np.int32).astype(np.float32)), 1)
 
