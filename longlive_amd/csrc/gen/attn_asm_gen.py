@@ -119,6 +119,8 @@ S_ONES = 46                                  # (1.0, 1.0) in bf16 for DOT_LSUM
 PK_LSUM = KNOB("PK_LSUM", 0)                 # LSUM = 0: row sums by v_pk_add_f32 on element pairs (two pair-accumulators per q-block) instead of v_add_f32 per element
 ADD_LATE = KNOB("ADD_LATE", 0)               # LSUM = 0: the adds of the elements whose registers survive the in-place pack (registers
                                              # 8..15 of every score tile) are issued in phase B instead of phase A
+DIAG_PRO = KNOB("DIAG_PRO", 0)               # with --diag: instead of the per-phase sums, eight s_memrealtime stamps (100 MHz) of the kernel's TIMELINE per wave
+                                             # (entry, staging issued, Q + tiles landed, Q converted, loop start, loop end, stores issued, stores done) -> dbg[64 B]
 S_TS, S_ACC = 60, 64                         # last stamp s[60:61]; sums s[64:65] A, s[66:67] B, s[68:69] wait+barrier, s[70:71] whole loop
 
 A_O, A_Q, A_K = 0, 128, 192
@@ -421,6 +423,7 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
     g = Gen()
     I = g.I
     # ================= setup =================
+    pstamp(g, 0)
     I(f"v_and_b32 {vreg(V_LANE)}, 63, {vreg(V_TID)}")
     I(f"v_lshrrev_b32 {vreg(V_T)}, 6, {vreg(V_TID)}")
     I("s_nop 0")
@@ -473,6 +476,7 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
         if t < 3:
             for op in dma_pieces("V", t) + dma_step("V"):
                 I(op)
+    pstamp(g, 1)
     # idle waves (all 64 rows of the wave are padding) only stage and synchronise
     I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_WAVE)}, 6")
     I(f"s_cmp_ge_u32 {sreg(S_T0)}, {sreg(S_ROWS)}")
@@ -530,6 +534,7 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
         for k in range(4):
             I(f"v_mov_b32 {vreg(V_ONES + k)}, 0x3f803f80")
     I("s_waitcnt vmcnt(0)")                           # Q, and every staged tile of the prologue
+    pstamp(g, 2)
     if qnorm:
         gen_qnorm_convert(g)
     for qb in range(0 if qnorm else 2):
@@ -543,6 +548,7 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
                 I(f"v_mul_f32 {vreg(hi)}, {sreg(S_C)}, {vreg(hi)}")
                 I(f"v_cvt_pk_bf16_f32 {vreg(lo)}, {vreg(lo)}, {vreg(hi)}")
                 I(f"v_accvgpr_write_b32 {areg(A_Q + 32 * qb + 4 * ks + j)}, {vreg(lo)}")
+    pstamp(g, 3)
     I("s_barrier")                                    # (1) every wave's share of K(0..3), V(0..2) is in LDS
     # ---- tile 0: K(0) -> AGPRs, S(0) from zero, exact row max -> m_ref, NM, S -= m_ref
     for op in k_frag_reads(0):
@@ -566,7 +572,8 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
     I("s_waitcnt lgkmcnt(0)")
     I("s_barrier")                                    # (2) K(0) has been read by every wave: its slot may be refilled
     I(f"s_mov_b32 {sreg(S_I)}, 1")
-    if DIAG:
+    pstamp(g, 4)
+    if DIAG and not DIAG_PRO:
         for k in range(8):
             I(f"s_mov_b32 {sreg(S_ACC + k)}, 0")
         stamp(g)
@@ -604,7 +611,8 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
     g.L("LL_EPILOGUE")
     I("s_nop 15")
     I("s_nop 15")
-    if DIAG:
+    pstamp(g, 5)
+    if DIAG and not DIAG_PRO:
         stamp(g)
         I(f"s_sub_u32 {sreg(S_ACC + 6)}, {sreg(S_TS)}, s72")
         I(f"s_subb_u32 {sreg(S_ACC + 7)}, {sreg(S_TS + 1)}, s73")
@@ -620,7 +628,22 @@ def generate(dma: str = "buffer", prefix: str = "LL", diag: bool = False, qnorm:
         I(f"global_store_dwordx4 {vreg(V_T)}, {vreg(V_T + 6, 4)}, {sreg(S_DBG, 2)} offset:16")
         I("s_mov_b64 exec, -1")
     gen_epilogue(g)
+    pstamp(g, 6)
     I("s_waitcnt vmcnt(0)")
+    pstamp(g, 7)
+    if DIAG and DIAG_PRO:                             # the eight stamps -> dbg + 64 * (4 * workgroup + wave)
+        I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_WG)}, 2")
+        I(f"s_add_u32 {sreg(S_T0)}, {sreg(S_T0)}, {sreg(S_WAVE)}")
+        I(f"s_lshl_b32 {sreg(S_T0)}, {sreg(S_T0)}, 6")
+        I(f"v_mov_b32 {vreg(V_T)}, {sreg(S_T0)}")
+        I(f"v_cmp_eq_u32_e64 {sreg(S_M0, 2)}, {vreg(V_LANE)}, 0")
+        I(f"s_mov_b64 exec, {sreg(S_M0, 2)}")
+        for q4 in range(4):
+            for k in range(4):
+                I(f"v_mov_b32 {vreg(V_T + 2 + k)}, {sreg(64 + 4 * q4 + k)}")
+            I(f"global_store_dwordx4 {vreg(V_T)}, {vreg(V_T + 2, 4)}, {sreg(S_DBG, 2)} offset:{16 * q4}")
+        I("s_mov_b64 exec, -1")
+        I("s_waitcnt vmcnt(0)")
     I("s_endpgm")
     # ================= idle waves =================
     g.L("LL_IDLE")
@@ -716,9 +739,16 @@ def mask_rets(x):
     return [f"LL_MASK_RET_{u}" for u in ((0, 2) if x == 0 else (1, 3))]
 
 
+def pstamp(g: Gen, k: int):
+    """timeline stamp k (DIAG_PRO builds only) into s[64 + 2k : 65 + 2k]"""
+    if DIAG and DIAG_PRO:
+        g.I(f"s_memrealtime {sreg(64 + 2 * k, 2)}")
+        g.I("s_waitcnt lgkmcnt(0)")
+
+
 def stamp(g: Gen, acc=None):
     """diagnostic: s[62:63] = now; if acc: acc += now - last; last = now"""
-    if not DIAG:
+    if not DIAG or DIAG_PRO:
         return
     g.I("s_memtime s[62:63]")
     g.I("s_waitcnt lgkmcnt(0)")

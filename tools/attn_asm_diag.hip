@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
   bf16* v = (bf16*)dalloc((size_t)Lk * C * 2, 0.7f);
   bf16* o; CK(hipMalloc(&o, (size_t)Lq * C * 2));
   const int nqt = (Lq + 255) / 256, nwg = nqt * H;
-  unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)nwg * 4 * 32)); CK(hipMemset(dbg, 0, (size_t)nwg * 4 * 32));
+  unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)nwg * 4 * 64)); CK(hipMemset(dbg, 0, (size_t)nwg * 4 * 64));
   CK(hipFuncSetAttribute((const void*)flash_attn_asm_d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   const float c = 0.08838834764831845f * 1.4426950408889634f;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -52,9 +52,34 @@ int main(int argc, char** argv) {
   }
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const int nt = (Lk + 63) / 64;
+#ifdef LL_DIAG_PRO
+  // timeline build (ASM_DIAG_PRO=1): eight s_memrealtime stamps (100 MHz) per wave -> where a launch's time goes outside the tile loop
+  {
+    std::vector<unsigned long long> t((size_t)nwg * 4 * 8);
+    CK(hipMemcpy(t.data(), dbg, t.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[7] = {"setup + staging issue", "Q loads issued -> Q and first tiles landed", "Q convert (+ norm)", "tile 0 + K(1) + barriers",
+                            "tile loop (tiles 1 .. nt-1) + tail", "epilogue (normalise, pack, store issue)", "stores acknowledged"};
+    unsigned long long first = ~0ull, last = 0;
+    std::vector<double> d[7];
+    for (int g = 0; g < nwg * 4; ++g) {
+      unsigned long long* r = &t[(size_t)g * 8];
+      if (r[7] == 0) continue;                       // idle wave
+      if (r[0] < first) first = r[0];
+      if (r[7] > last) last = r[7];
+      for (int k = 0; k < 7; ++k) d[k].push_back((double)(r[k + 1] - r[k]) * 0.01);
+    }
+    auto med = [](std::vector<double> x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
+    printf("timeline build: %.1f us per launch by events; first wave entry -> last wave done %.1f us; %d workgroups, %d key tiles; per wave (median, us):\n",
+           ms * 1e3 / iters, (double)(last - first) * 0.01, nwg, nt);
+    double sum = 0;
+    for (int k = 0; k < 7; ++k) { printf("  %-46s %6.2f\n", names[k], med(d[k])); sum += med(d[k]); }
+    printf("  %-46s %6.2f\n", "sum (one wave's life)", sum);
+    return 0;
+  }
+#endif
   std::vector<unsigned long long> h((size_t)nwg * 16);
   CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-  const int nt = (Lk + 63) / 64;
   printf("diag build: %.1f us per launch (stamped: not the kernel's real time), %d workgroups, %d tiles\n", ms * 1e3 / iters, nwg, nt);
   for (int w = 0; w < 4; ++w) {
     std::vector<double> a, b, s, tot;
