@@ -63,7 +63,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernels table and the side numbers after the timed region")
-    ap.add_argument("--cpu-layers", type=int, default=2, help="layers of one steady-state forward timed on the CPU")
+    ap.add_argument("--cpu-layers", type=int, default=30, help="layers of one steady-state forward timed on the CPU (30 = the whole forward, ~20 s)")
     ap.add_argument("--workload", choices=["dit", "vae", "t5"], default="dit",
                     help="dit (default): the headline metric.  vae / t5: the section-8f rows (VAE decoder, umT5 encoder) with "
                          "their own roofline and cpu_baseline objects; single GPU, not the driver's metric")
@@ -75,21 +75,24 @@ def parse(argv=None):
 
 
 # ---- CPU baselines (the only place outside tests/ and smoke() that may run the oracle) --------------------------------
-def cpu_baseline(num_layers_sample: int):
-    """Times the CPU oracle on `num_layers_sample` of the 30 layers of ONE steady-state DiT forward (L = 4680 query
-    tokens, full 18720-slot KV cache, roll + insert) and extrapolates to a block (x 30/sample layers x 5 forwards)."""
+def cpu_baseline(num_layers_sample: int, dev=None):
+    """Times the CPU oracle on ONE steady-state DiT forward (L = 4680 query tokens, full 18720-slot KV cache, roll + insert) --
+    all 30 layers by default (~20 s on the GPU box's 16 host cores) -- and scales to a block (x 5 forwards; x 30 / sample layers when
+    fewer layers are asked for).  The synthetic weights and cache contents are hashed on the GPU when one is given (bit-identical to
+    the CPU hash, which would take minutes for 1.4 G values) and copied to the host; the timed region is the oracle's forward only."""
     from longlive_amd import synth
     from oracle import ref_model as RM
 
+    gdev = dev if dev is not None else "cpu"
     cfg = synth.longlive_1_3b(num_layers=num_layers_sample)
-    sd = synth.synth_state_dict(cfg, seed=0, layers=list(range(num_layers_sample)))
+    sd = {k: v.cpu() for k, v in synth.synth_state_dict(cfg, seed=0, layers=list(range(num_layers_sample)), device=gdev).items()}
     fs = cfg.frame_seqlen
     S = 12 * fs
     m = RM.RefModel(RM.RefConfig.from_cfg(cfg), sd, frame_seqlen_for_max_attn=fs)
     kv = RM.new_kv_cache(1, S, num_layers_sample, 12, 128)
     for i, c in enumerate(kv):
-        c["k"] = synth.hash_normal(61, f"kv.{i}.k", (1, S, 12, 128)).to(torch.bfloat16)
-        c["v"] = (0.5 * synth.hash_normal(61, f"kv.{i}.v", (1, S, 12, 128))).to(torch.bfloat16)
+        c["k"] = synth.hash_normal(61, f"kv.{i}.k", (1, S, 12, 128), device=gdev).to(torch.bfloat16).cpu()
+        c["v"] = (0.5 * synth.hash_normal(61, f"kv.{i}.v", (1, S, 12, 128), device=gdev)).to(torch.bfloat16).cpu()
         c["global_end_index"] = S
         c["local_end_index"] = S
     ca = RM.new_crossattn_cache(1, 512, num_layers_sample, 12, 128)
@@ -105,9 +108,10 @@ def cpu_baseline(num_layers_sample: int):
     dt = time.perf_counter() - t0
     fwd = dt * 30.0 / num_layers_sample            # embeddings/head are <0.1% of a forward
     block = 5.0 * fwd
+    what = ("one full steady-state DiT forward (30 layers" if num_layers_sample == 30 else f"{num_layers_sample} of 30 layers of one steady-state DiT forward (")
+    scale = "x5 forwards per 12-frame block" if num_layers_sample == 30 else f"x{30 / num_layers_sample:.0f} layers x5 forwards per 12-frame block"
     return dict(value=3 * PIXEL_FRAMES_PER_LATENT / block, unit="frames/s", cores=threads, kind="port",
-                sample=f"{num_layers_sample} of 30 layers of one steady-state DiT forward (L=4680, Lk=18720) in "
-                       f"{dt:.2f}s on {threads} threads, x{30 / num_layers_sample:.0f} layers x5 forwards per 12-frame block")
+                sample=f"{what}, L=4680, Lk=18720) timed in {dt:.2f}s on {threads} threads, {scale}")
 
 
 def cpu_baseline_vae(vae, lat):
@@ -678,7 +682,9 @@ def run_replica(args, rank, world, local_rank, sync):
             res["extras"] = {"error": repr(exc)}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_layers)
+            del gen                                                    # (the GPU model is no longer needed: the host copy of the weights is the oracle's)
+            torch.cuda.empty_cache()
+            res["cpu_baseline"] = cpu_baseline(args.cpu_layers, dev)
         except Exception as exc:      # the baseline is reporting only; never lose the GPU number over it
             res["cpu_baseline"] = {"error": repr(exc)}
     return res

@@ -333,13 +333,15 @@ def t5_param_shapes(cfg: T5Config) -> Dict[str, Tuple[int, ...]]:
     return sh
 
 
-def synth_t5_state_dict(cfg: T5Config, seed: int = 0, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+def synth_t5_state_dict(cfg: T5Config, seed: int = 0, device="cpu", dtype=torch.bfloat16, only: str = None) -> Dict[str, torch.Tensor]:
     """Random-init with the reference's init statistics (init_weights, t5.py:27-44); deviations so every term matters:
     norm weights 1 + N(0,.1), q weights 8x larger (the reference's (dim*dim_attn)^-.5 makes all logits ~0), position
     embeddings N(0, 1) (the reference's std .016 would make the relative bias invisible in bf16 parity)."""
     head_dim = cfg.dim_attn // cfg.num_heads
     sd = {}
     for name, shape in t5_param_shapes(cfg).items():
+        if only is not None and name != only:           # one tensor of a model too large to hold twice (the 24-layer golden)
+            continue
         z = hash_normal(seed, "t5." + name, shape, device)
         if name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
             w = 1.0 + 0.1 * z

@@ -629,6 +629,38 @@ def gen_t5(ns):
     _save("t5_enc.pt", rec)
 
 
+def gen_t5_deep(ns):
+    """The umT5-xxl encoder at its FULL depth: 24 layers at the real widths (dim 4096, 64 heads, ffn 10240, L = 512; a 4096-entry
+    vocabulary keeps the embedding table small), the reference's own umt5_xxl(encoder_only=True) in bf16 on synthetic weights.  Only
+    the final context is stored (4 MiB) plus the residual stream's per-layer RMS as a drift check.  ~5 min and ~25 GB here: the
+    model is built in bf16 directly (the weights are bf16 values either way: loading them as fp32 and casting gives the same bits)."""
+    import importlib
+    t5 = importlib.import_module("wan.modules.t5")
+    cfg = synth.T5Config(vocab_size=4096, num_layers=24)
+    t0 = time.time()
+    model = t5.umt5_xxl(encoder_only=True, return_tokenizer=False, dtype=torch.bfloat16, device=torch.device("cpu"),
+                        vocab_size=cfg.vocab_size, dim=cfg.dim, dim_attn=cfg.dim_attn, dim_ffn=cfg.dim_ffn,
+                        num_heads=cfg.num_heads, encoder_layers=cfg.num_layers).eval().requires_grad_(False)
+    own = model.state_dict()
+    for name, shape in synth.t5_param_shapes(cfg).items():           # one tensor at a time: never two copies of the model
+        one = synth.synth_t5_state_dict(cfg, seed=7, only=name)[name]
+        assert own[name].shape == one.shape and own[name].dtype == torch.bfloat16, name
+        own[name].copy_(one)
+    print(f"t5 deep: weights in {time.time() - t0:.1f}s")
+    ids, mask = synth.synth_token_ids(cfg, 77, seed=3, batch=1)
+    rms = []
+    hooks = [blk.register_forward_hook(lambda m, i, o: rms.append(float(o.float().pow(2).mean().sqrt()))) for blk in model.blocks]
+    t0 = time.time()
+    ctx = model(ids, mask)
+    for h in hooks:
+        h.remove()
+    seq_lens = mask.gt(0).sum(dim=1).long()
+    for u, v in zip(ctx, seq_lens):
+        u[v:] = 0.0
+    print(f"t5 deep: forward {time.time() - t0:.1f}s", tuple(ctx.shape), float(ctx.float().std()), [round(r, 2) for r in rms])
+    _save("t5_enc_deep.pt", dict(out=ctx.clone(), ntok=77, layer_rms=rms))
+
+
 W_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,
           -0.1922, -0.9497, 0.2503, -0.2921]
 W_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382,
