@@ -24,6 +24,8 @@ import torch
 
 _M64 = (1 << 64) - 1
 FORCE_TORCH_HASH = False       # tests: evaluate the hash with int64 tensor ops on the GPU too (the path ll_synth_hash replaces)
+CPU_HASH = None                # optional accelerator for the CPU path, same integers (oracle/fast_hash.py installs a host build of
+                               # csrc/synth_hash.h: the golden generators and the slow oracle tests hash billions of weights)
 
 
 def _s64(x: int) -> int:
@@ -73,6 +75,8 @@ def hash_uniform(seed: int, name: str, shape, device="cpu", chunk: int = 1 << 26
     s = _stream(seed, name)
     if torch.device(device).type == "cuda" and not FORCE_TORCH_HASH:
         return _device_hash(0, s, numel, device).view(*shape)
+    if torch.device(device).type == "cpu" and CPU_HASH is not None and not FORCE_TORCH_HASH:
+        return CPU_HASH(0, s, numel).view(*shape)
     out = torch.empty(numel, dtype=torch.float32, device=device)
     for lo in range(0, numel, chunk):
         hi = min(numel, lo + chunk)
@@ -88,6 +92,8 @@ def hash_normal(seed: int, name: str, shape, device="cpu", chunk: int = 1 << 25)
     s = _stream(seed, name)
     if torch.device(device).type == "cuda" and not FORCE_TORCH_HASH:
         return _device_hash(1, s, numel, device).view(*shape)
+    if torch.device(device).type == "cpu" and CPU_HASH is not None and not FORCE_TORCH_HASH:
+        return CPU_HASH(1, s, numel).view(*shape)
     out = torch.empty(numel, dtype=torch.float32, device=device)
     for lo in range(0, numel, chunk):
         hi = min(numel, lo + chunk)

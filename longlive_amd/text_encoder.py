@@ -112,19 +112,32 @@ class UMT5EncoderHIP(nn.Module):
             if n < 1 or not bool((m[:n] > 0).all()):
                 raise RuntimeError("UMT5EncoderHIP: mask must be a non-empty prefix (right-padded prompts)")
             x = ops.gather_rows(self._p("token_embedding.weight"), ids_d[b].contiguous())
-            h = ops.t5_rmsnorm(x, self._layers[0]["n1"])
-            for i, ly in enumerate(self._layers):
-                qk = ops.gemm(h, ly["wqk"], zq[2 * c.dim_attn])
-                vt = ops.gemm(ly["wv"], h, zq[L])                                    # [dim_attn, L] = Wv h^T
-                a = ops.t5_attention(qk, vt, ly["bias"], c.num_heads, n)
-                # x = x + o(a); h = norm2(x)   and   x = x + w2(g); h = the next layer's norm1(x) (the encoder's final norm after
-                # the last layer): the residual update and the norm that follows it are one call (same bits as the two kernels)
-                x, h = ops.gemm_res_t5norm(a, ly["wo"], zq[c.dim], x, ly["n2"])
-                g = ops.t5_gated_gelu(ops.gemm(h, ly["wgf"], zq[2 * c.dim_ffn]))
-                nxt = self._layers[i + 1]["n1"] if i + 1 < len(self._layers) else self._p("norm.weight")
-                x, h = ops.gemm_res_t5norm(g, ly["w2"], zq[c.dim], x, nxt)
+            _, h = self.run_layers(x, n, 0, len(self._layers))
             outs.append(h)
         return torch.stack(outs, 0)
+
+    def run_layers(self, x: torch.Tensor, n_valid: int, first: int, last: int):
+        """Layers [first, last) on the residual stream x [L, dim] of ONE prompt with n_valid unpadded positions -> (x after layer
+        last - 1, the norm that follows it applied: layer `last`'s norm1, or the encoder's final norm after the last layer).
+        forward() is run_layers(embedding, n, 0, num_layers); the tests enter mid-stack with the reference's own hidden states."""
+        c = self.cfg
+        if not self._packed:
+            self._pack()
+        L = x.shape[0]
+        zq = self._zeros
+        h = ops.t5_rmsnorm(x, self._layers[first]["n1"])
+        for i in range(first, last):
+            ly = self._layers[i]
+            qk = ops.gemm(h, ly["wqk"], zq[2 * c.dim_attn])
+            vt = ops.gemm(ly["wv"], h, zq[L])                                    # [dim_attn, L] = Wv h^T
+            a = ops.t5_attention(qk, vt, ly["bias"], c.num_heads, n_valid)
+            # x = x + o(a); h = norm2(x)   and   x = x + w2(g); h = the next layer's norm1(x) (the encoder's final norm after
+            # the last layer): the residual update and the norm that follows it are one call (same bits as the two kernels)
+            x, h = ops.gemm_res_t5norm(a, ly["wo"], zq[c.dim], x, ly["n2"])
+            g = ops.t5_gated_gelu(ops.gemm(h, ly["wgf"], zq[2 * c.dim_ffn]))
+            nxt = self._layers[i + 1]["n1"] if i + 1 < len(self._layers) else self._p("norm.weight")
+            x, h = ops.gemm_res_t5norm(g, ly["w2"], zq[c.dim], x, nxt)
+        return x, h
 
 
 class WanTextEncoder(nn.Module):

@@ -427,6 +427,8 @@ def gen_real_recache(ns):
 
 
 def main(argv):
+    from oracle import fast_hash
+    fast_hash.install()                                # the same integers, ~100x faster on the CPU (host build of csrc/synth_hash.h)
     ns = load_pipelines()
     todo = argv or ["ops", "toy", "pipe", "pipe_calls", "real_block", "real_fwd"]
     for t in todo:
@@ -648,8 +650,17 @@ def gen_t5_deep(ns):
         own[name].copy_(one)
     print(f"t5 deep: weights in {time.time() - t0:.1f}s")
     ids, mask = synth.synth_token_ids(cfg, 77, seed=3, batch=1)
-    rms = []
-    hooks = [blk.register_forward_hook(lambda m, i, o: rms.append(float(o.float().pow(2).mean().sqrt()))) for blk in model.blocks]
+    rms, mids = [], {}
+    keep = (5, 11, 17, 23)                             # residual stream after layers 6, 12, 18, 24: the valid rows only (the padded ones never feed them)
+
+    def hook(i):
+        def f(m, inp, o):
+            rms.append(float(o.float().pow(2).mean().sqrt()))
+            if i in keep:
+                mids[i + 1] = o[0, :77].clone()
+        return f
+    hooks = [blk.register_forward_hook(hook(i)) for i, blk in enumerate(model.blocks)]
+    emb = model.token_embedding(ids)[0, :77].clone()   # the residual stream that enters layer 0 (dropout is the identity in eval)
     t0 = time.time()
     ctx = model(ids, mask)
     for h in hooks:
@@ -658,7 +669,7 @@ def gen_t5_deep(ns):
     for u, v in zip(ctx, seq_lens):
         u[v:] = 0.0
     print(f"t5 deep: forward {time.time() - t0:.1f}s", tuple(ctx.shape), float(ctx.float().std()), [round(r, 2) for r in rms])
-    _save("t5_enc_deep.pt", dict(out=ctx.clone(), ntok=77, layer_rms=rms))
+    _save("t5_enc_deep.pt", dict(out=ctx.clone(), ntok=77, layer_rms=rms, x_in=emb, x_after=mids))
 
 
 W_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,

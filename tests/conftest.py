@@ -13,6 +13,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "slow: real-shape CPU oracle checks (minutes); set LONGLIVE_SLOW=1")
+    # synthetic weights / inputs on the CPU through a host build of csrc/synth_hash.h: the same integers as synth's int64 tensor form
+    # (tests/test_synth_hash.py holds the two against each other), ~100x faster; silently absent without g++
+    try:
+        from oracle import fast_hash
+        fast_hash.install()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

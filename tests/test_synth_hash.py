@@ -37,5 +37,26 @@ def test_host_build_of_the_hash_header_equals_synth(tmp_path):
         for kind, fn in ((0, synth.hash_uniform), (1, synth.hash_normal)):
             raw = subprocess.run([str(exe), str(s), "0", str(n), str(kind)], check=True, capture_output=True).stdout
             got = np.frombuffer(raw, dtype=np.float32)
-            ref = fn(seed, name, (n,)).numpy()
+            try:
+                synth.FORCE_TORCH_HASH = True               # the int64 TENSOR form, not the accelerated CPU path conftest installs
+                ref = fn(seed, name, (n,)).numpy()
+            finally:
+                synth.FORCE_TORCH_HASH = False
             assert got.shape == ref.shape and (got.view(np.uint32) == ref.view(np.uint32)).all(), (seed, name, kind)
+
+
+def test_accelerated_cpu_hash_equals_the_tensor_form():
+    """oracle/fast_hash.py (what conftest and oracle/make_golden.py install for the CPU path) against the tensor form."""
+    from oracle import fast_hash
+    if not fast_hash.install():
+        import pytest
+        pytest.skip("no g++ here")
+    for seed, name, shape in ((0, "blocks.0.ffn.0.weight", (301, 77)), (5, "noise", (3, 16, 7, 11))):
+        for fn in (synth.hash_uniform, synth.hash_normal):
+            fast = fn(seed, name, shape)
+            try:
+                synth.FORCE_TORCH_HASH = True
+                ref = fn(seed, name, shape)
+            finally:
+                synth.FORCE_TORCH_HASH = False
+            assert torch.equal(fast, ref), (seed, name, fn.__name__)
