@@ -114,7 +114,7 @@ def test_t5_encoder_full_depth_vs_reference_golden():
     T5Encoder's own bf16 CPU run (tests/golden/t5_enc_deep.pt, oracle/make_golden.py t5_deep: final context + the residual stream
     of the valid rows after layers 6 / 12 / 18 / 24).
     (a) teacher-forced: every 6-layer segment entered with the REFERENCE's hidden state must land on the reference's next state
-        (rel-L2 < 2.5e-2: the 2-layer run measures 7.6e-3); a wrong layer, weight or bias table anywhere in the stack fails here;
+        (rel-L2 < 3e-2, measured 2.4e-2 at worst; the 2-layer run measures 7.6e-3); a wrong layer, weight or bias table anywhere in the stack fails here;
     (b) free-running over all 24 layers the two implementations' bf16 rounding differences are amplified ~5 % per layer by this
         random-weight stack (1.0e-1 measured, cosine 0.9945): held to 1.5e-1 / 0.99, finite, padding rows zero."""
     if not os.path.exists(os.path.join(GOLDEN, "t5_enc_deep.pt")):
@@ -132,10 +132,10 @@ def test_t5_encoder_full_depth_vs_reference_golden():
         xo, h = enc.text_encoder.run_layers(x, n, first, first + 6)
         r = rel_l2(xo[:n].cpu(), states[first + 6])
         worst = max(worst, r)
-        assert r < 2.5e-2, (first, r)
+        assert r < 3e-2, (first, r)
         if first == 18:                                       # the encoder's final norm follows layer 23
             rf = rel_l2(h[:n].cpu(), rec["out"][0, :n])
-            assert rf < 2.5e-2, rf
+            assert rf < 3e-2, rf
     got = enc.encode_ids(ids, mask)["prompt_embeds"].cpu()
     want = rec["out"]
     r = rel_l2(got, want)
