@@ -3,7 +3,7 @@
 #   bash tools/gpu_batch.sh <outdir-name> step [step ...]
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
-#   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | bench | bench_short | trace | pmc_bench | pmc_inpipe
+#   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | tuned=<LL_TUNING_TEST spec> | bench | bench_short | trace | pmc_bench | pmc_inpipe
 #   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
 set -u
 cd "$(dirname "$0")/.." || exit 1
@@ -34,6 +34,9 @@ for step in "$@"; do
     tests)
       if [ -n "$arg" ]; then timeout -k 10 1100 python -m pytest tests -m gpu -q -x -k "$arg" > $O/gputests.log 2>&1; else timeout -k 10 1100 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1; fi
       rc=$?; echo "pytest rc=$rc"; tail -5 $O/gputests.log; [ $rc -ne 0 ] && { cp $O/gputests.log $O/FAILED_gputests.log; grep -E "^(FAILED|ERROR)|Error|fault" $O/gputests.log | head -20; } ;;
+    tuned)         # the model-level GPU suites under a kernel-family override: tuned=gemm_asm=0,attn_asm=0  (LL_TUNING_TEST)
+      LL_TUNING_TEST="$arg" timeout -k 10 1100 python -m pytest tests/test_model_gpu.py tests/test_boundary_gpu.py tests/test_checkpoint.py -m gpu -q > $O/tuned_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').log 2>&1
+      rc=$?; echo "pytest rc=$rc"; tail -4 $O/tuned_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').log ;;
     testfile)
       f=${arg%%::*}; k=""; [ "$f" != "$arg" ] && k=${arg#*::}
       if [ -n "$k" ]; then timeout -k 10 900 python -m pytest $f -m gpu -q -x -s -k "$k" > $O/test_$(basename $f .py).log 2>&1; else timeout -k 10 900 python -m pytest $f -m gpu -q -x -s > $O/test_$(basename $f .py).log 2>&1; fi
