@@ -286,7 +286,7 @@ class CausalWanModelHIP(nn.Module):
                       cac: dict, F: int, grid_hw: Tuple[int, int], current_start: int,
                       sink_recache_after_switch: bool = False, q_buf: Optional[torch.Tensor] = None,
                       kv_insert_only: bool = False, pk: Optional[dict] = None, premod: bool = False,
-                      cache_done_event=None) -> KVPlan:
+                      cache_done_event=None, co_running: bool = False) -> KVPlan:
         """CausalWanAttentionBlock.forward (causal_model.py:413-477) for block `i`: updates the residual stream
         xs [B, L, C] IN PLACE (L = F * hp * wp tokens, grid_hw = (hp, wp) tokens per frame) and this layer's KV / cross
         caches, returns the layer's KV plan (the caller commits the end indices after all layers,
@@ -337,7 +337,9 @@ class CausalWanModelHIP(nn.Module):
             if cache_done_event is not None:
                 cache_done_event.record(torch.cuda.current_stream())
             return plan
-        att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self")
+        # (a forward that runs beside another one on a second stream -- the pipelines' context-pass overlap -- times its launches
+        #  under another tag: bench.py's roofline describes the kernel running alone on the device)
+        att = ops.flash_attn(q_buf, kvc["k"], kvc["v"], plan.segments, tag="flash_attn_self_co" if co_running else "flash_attn_self")
         if cache_done_event is not None:
             cache_done_event.record(torch.cuda.current_stream())
         self._lin(att.view(B, L, C), pk, "o", sa.o.weight, sa.o.bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
@@ -412,7 +414,8 @@ class CausalWanModelHIP(nn.Module):
             plans.append(self.block_forward(i, xs, etab[i] if premod else e0, ctx, kv_cache[i], crossattn_cache[i], F, (hp, wp),
                                             current_start, sink_recache_after_switch, q_buf,
                                             kv_insert_only=kv_only and i == last, pk=P[i], premod=premod,
-                                            cache_done_event=layer_record[i] if layer_record is not None else None))
+                                            cache_done_event=layer_record[i] if layer_record is not None else None,
+                                            co_running=cur_stream is not None))
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)

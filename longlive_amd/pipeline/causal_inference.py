@@ -56,10 +56,12 @@ class CausalInferencePipeline(nn.Module):
         # NEXT block's first denoising forward -- whose input is fresh noise -- runs on the main stream one layer behind it
         # (per-layer events: layer i of the follower waits until the context pass has left layer i's cache).  Same kernels on
         # the same data in the same per-cache order: bit-identical results (tests/test_model_gpu.py).  One stream's low-power
-        # phases (epilogues, row kernels, launch ramps) then overlap the other's dense kernels.
-        # Opt-in (+0.65 % frames/s measured): off by default so that per-kernel timings and the bench's roofline figure describe
-        # kernels running alone on the device.
-        self.overlap_context = False
+        # phases (epilogues, row kernels, launch ramps) and the CUs its 228-workgroup attention leaves idle then overlap the other's
+        # dense kernels: +1.55 % frames/s with round 4's kernels (profiles/r04_ab_overlap_context.md).
+        # ON by default since round 4 (generators that cannot run kv_only with per-layer events take the one-stream path);
+        # `overlap_context = False` -- or LL_OVERLAP=0 for bench.py -- gives the one-stream schedule, which is what bench.py's
+        # per-kernel table and roofline figure are measured on (kernels running alone on the device).
+        self.overlap_context = True
         self.overlap_decode = False      # inference(): decode each block on a second stream while the next one is generated (same video, bit for bit)
         self._aux = None
         self._ctx_events = None

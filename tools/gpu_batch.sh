@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | tuned=<LL_TUNING_TEST spec> | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
+#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -102,6 +102,13 @@ PY
         echo -n "[shipped] "; timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
         echo -n "[$v] "; LD_LIBRARY_PATH=experiments/r04/libs/$v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
       done | tee -a $O/ablib_$v.txt ;;
+    abbenchenv)    # interleaved A/B of bench.py under an environment switch: abbenchenv=<ENV=..>[/rounds]
+      v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
+      for i in $(seq 1 $n); do for t in "" "$v"; do
+        env $t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abe_$i.json 2> $O/abe_$i.err
+        rc=$?; dead $rc && break 2
+        echo -n "[${t:-shipped}] "; benchline $O/abe_$i.json
+      done; done | tee -a $O/abbenchenv.txt ;;
     abbench)       # the same with bench.py: abbench=<name>[/rounds]
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
       for i in $(seq 1 $n); do for t in "" "experiments/r04/libs/$v/liblonglive_hip.so"; do
