@@ -708,6 +708,9 @@ def final_record(args, world, per_replica, res0):
         "config": {"workload": WORKLOAD, "frames_per_step": 3 * PIXEL_FRAMES_PER_LATENT,
                    "ms_per_latent_frame": 1e3 * elapsed / args.steps / 3, "replicas": world,
                    "parallelism": f"replicas x{world} (no collective on the data path, no RCCL)",
+                   "schedule": ("two HIP streams per replica: a block's clean-context forward runs beside the next block's first denoising "
+                                "forward (pipeline default, bit-identical to one stream; LL_OVERLAP=0 = one stream)")
+                               if res0.get("overlap_context") else "one HIP stream per replica",
                    "per_replica_fps": [r["frames"] / r["elapsed"] for r in sorted(per_replica, key=lambda r: r["rank"])],
                    "per_replica_visible_devices": [r.get("visible") for r in sorted(per_replica, key=lambda r: r["rank"])]},
         "roofline": res0.get("roofline"), "cpu_baseline": res0.get("cpu_baseline"),
