@@ -444,33 +444,40 @@ def run_extras(gen, pipe_cls, interactive_cls, cfg, dev, budget_s=75.0):
     except Exception as exc:
         ex["batch2_fps"] = {"error": repr(exc)}
 
-    try:                                                     # config 5's throughput mode, second form: two B = 1 streams on two HIP streams
+    def two_streams(quant, blocks=6):                        # config 5's throughput mode: two B = 1 streams on two HIP streams of this process
         from longlive_amd.pipeline import InterleavedStreams
-        blocks = 6
-        pipes = [pipe_cls(_pipe_args(), dev, generator=gen) for _ in (0, 1)]
-        runner = InterleavedStreams(pipes, dev)
-        noises = [synth.synth_noise(cfg, 3 * (4 + blocks), seed=s, device=dev) for s in (0, 1)]
-        prompts = [{"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + s, device=dev)} for s in (0, 1)]
-        st = runner.stream(noises, prompts)
-        for _ in range(4):
-            next(st)
-        torch.cuda.synchronize()
-        tele2 = Telemetry(dev.index or 0)
-        tele2.start()
-        t0 = time.perf_counter()
-        for _ in range(blocks):
-            next(st)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        t2 = tele2.stop(dev.index or 0) or {}
-        ex["two_stream_fps"] = {"value": 2 * 12 * blocks / dt, "unit": "frames/s (both streams together)", "ms_per_step": 1e3 * dt / blocks,
-                                "sclk_mhz_avg": t2.get("sclk_mhz_avg"), "power_w_avg": t2.get("power_w_avg"),
-                                "workload": "two independent B = 1 prompt streams on two HIP streams of one process, launches interleaved block by "
-                                            "block (pipeline/throughput.py), same steady-state blocks, bf16; each stream bit-identical to its solo "
-                                            "run (tests/test_model_gpu.py)"}
-        del st, runner, pipes, noises
-    except Exception as exc:
-        ex["two_stream_fps"] = {"error": repr(exc)}
+        gen.model.set_quant(quant)
+        try:
+            pipes = [pipe_cls(_pipe_args(), dev, generator=gen) for _ in (0, 1)]
+            runner = InterleavedStreams(pipes, dev)
+            noises = [synth.synth_noise(cfg, 3 * (4 + blocks), seed=s, device=dev) for s in (0, 1)]
+            prompts = [{"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=1 + s, device=dev)} for s in (0, 1)]
+            st = runner.stream(noises, prompts)
+            for _ in range(4):
+                next(st)
+            torch.cuda.synchronize()
+            tele2 = Telemetry(dev.index or 0)
+            tele2.start()
+            t0 = time.perf_counter()
+            for _ in range(blocks):
+                next(st)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            t2 = tele2.stop(dev.index or 0) or {}
+            del st, runner, pipes, noises
+            return {"value": 2 * 12 * blocks / dt, "unit": "frames/s (both streams together)", "ms_per_step": 1e3 * dt / blocks,
+                    "sclk_mhz_avg": t2.get("sclk_mhz_avg"), "power_w_avg": t2.get("power_w_avg"),
+                    "workload": "two independent B = 1 prompt streams on two HIP streams of one process, launches interleaved block by "
+                                "block (pipeline/throughput.py), same steady-state blocks, " + ("W8A8 block linears" if quant else "bf16") +
+                                "; each stream bit-identical to its solo run (tests/test_model_gpu.py)"}
+        finally:
+            gen.model.set_quant(None)
+
+    for key, quant in (("two_stream_fps", None), ("int8_two_stream_fps", "int8")):      # the second one is BASELINE config 5's own mode:
+        try:                                                                          # several prompt streams per GPU with INT8 linears
+            ex[key] = two_streams(quant)
+        except Exception as exc:
+            ex[key] = {"error": repr(exc)}
 
     try:                                                     # config 4: prompt switch = recache of the 12-frame window
         I = interactive_cls(_pipe_args(), dev, generator=gen)
