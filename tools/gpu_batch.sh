@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | tuned=<LL_TUNING_TEST spec> | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs
+#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs | nstreams[=<args>]
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -120,6 +120,8 @@ PY
       timeout -k 10 300 ./tools/kbench $arg 2>&1 | tee -a $O/kbench.txt; rc=${PIPESTATUS[0]} ;;
     configs)
       timeout -k 10 400 python tools/run_configs.py 240 > $O/configs34.json 2>$O/configs.err; rc=$?; echo "rc=$rc"; head -c 900 $O/configs34.json; echo ;;
+    nstreams)      # nstreams[=<extra args>]: N = 1..4 interleaved prompt streams (tools/nstreams.py)
+      timeout -k 10 600 python3 tools/nstreams.py $arg > $O/nstreams.json 2> $O/nstreams.err; rc=$?; echo "nstreams rc=$rc"; tail -c 700 $O/nstreams.json; echo ;;
     *) echo "unknown step $step"; rc=1 ;;
   esac
   if dead $rc; then echo "step $step died (rc $rc): batch stopped"; exit $rc; fi
