@@ -8,42 +8,86 @@
 
 #define MAXCH 4  // 4 * 64 lanes * 8 elements = 2048 columns max
 
+// These kernels are VALU-bound as much as HBM-bound (4.6 waves per SIMD, ~600 vector instructions per row before this form), so the
+// arithmetic runs on PAIRS of elements: a 32-bit word of the row is two bf16 values, unpack2 makes them an fp32 pair (shift / mask),
+// the fp32 steps are v_pk_mul_f32 / v_pk_add_f32 (two elements per instruction), and every bf16 rounding point of the reference is
+// one v_cvt_pk_bf16_f32 per pair (+ the shift / mask when the value is used again).  Same operations in the same order per element
+// as the scalar form: bit-identical results.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ f32x2 unpack2(unsigned u) {
+  f32x2 r;
+  r.x = __builtin_bit_cast(float, u << 16);
+  r.y = __builtin_bit_cast(float, u & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ unsigned pack2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 rbf2(f32x2 v) { return unpack2(pack2(v)); }
+__device__ __forceinline__ f32x2 splat2(float v) {
+  f32x2 r = {v, v};
+  return r;
+}
+
 struct RowRegs {
-  float v[MAXCH][8];
+  f32x2 p[MAXCH][4];      // chunk i of the lane: elements 2j, 2j + 1
+};
+struct RowWords {
+  unsigned w[MAXCH][4];   // the same as packed bf16 pairs
 };
 
-template <int NCH>
-__device__ __forceinline__ void load_row(const bf16* __restrict__ p, int C, int lane, RowRegs& r) {
+// FULL: C is a whole number of 512-column chunks (C == 512 NCH; the 1.3B model's 1536): every `chunk inside the row` test is true
+// at compile time, so a row's loads are issued together and waited for once -- with the test in place the compiler keeps each
+// load inside its own exec-masked branch and waits for it there.
+template <bool FULL>
+__device__ __forceinline__ bool in_row(int c, int C) {
+  return FULL || c < C;
+}
+
+template <int NCH, bool FULL>
+__device__ __forceinline__ void load_words(const bf16* __restrict__ p, int C, int lane, RowWords& r) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = (lane + 64 * i) * 8;
-    if (c < C) {
-      bf16x8 t = *reinterpret_cast<const bf16x8*>(p + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = (float)t[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
-    }
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+    if (in_row<FULL>(c, C)) t = *reinterpret_cast<const uint4*>(p + c);
+    r.w[i][0] = t.x, r.w[i][1] = t.y, r.w[i][2] = t.z, r.w[i][3] = t.w;
   }
 }
 
-template <int NCH>
-__device__ __forceinline__ void layernorm_stats(const RowRegs& r, int C, int lane, float eps, float& mean, float& rstd) {
+template <int NCH, bool FULL>
+__device__ __forceinline__ void load_row(const bf16* __restrict__ p, int C, int lane, RowRegs& r) {
+  RowWords w;
+  load_words<NCH, FULL>(p, C, lane, w);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.p[i][j] = unpack2(w.w[i][j]);
+}
+
+// mean and 1/sqrt(var + eps); on return r holds x - mean (what every consumer needs next).  Sums in element order, as before.
+template <int NCH, bool FULL>
+__device__ __forceinline__ void layernorm_center(RowRegs& r, int C, int lane, float eps, float& rstd) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += r.v[i][j];
-  mean = wave_sum(s) / (float)C;
+    for (int j = 0; j < 4; ++j) {
+      s += r.p[i][j].x;
+      s += r.p[i][j].y;
+    }
+  float mean = wave_sum(s) / (float)C;
+  f32x2 m2 = splat2(mean);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    if ((lane + 64 * i) * 8 < C) {
+    if (in_row<FULL>((lane + 64 * i) * 8, C)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float d = r.v[i][j] - mean;
-        q += d * d;
+      for (int j = 0; j < 4; ++j) {
+        f32x2 d = r.p[i][j] - m2;
+        r.p[i][j] = d;
+        f32x2 dd = d * d;
+        q += dd.x;
+        q += dd.y;
       }
     }
   }
@@ -51,30 +95,31 @@ __device__ __forceinline__ void layernorm_stats(const RowRegs& r, int C, int lan
   rstd = 1.0f / sqrtf(var + eps);
 }
 
-// Row output: bf16, or (int8 mode) symmetric per-row int8 + scale computed from the SAME bf16-rounded values the bf16
-// path would have stored, so fused and unfused quantisation are bit-identical (scale = max|y| / 127, q = rint(y / scale)).
-template <int NCH>
-__device__ __forceinline__ void emit_row(const RowRegs& y, int C, int lane, int row, bf16* __restrict__ out,
+// Row output from packed bf16 pairs: stored as they are, or (int8 mode) symmetric per-row int8 + scale computed from the SAME
+// bf16-rounded values the bf16 path stores, so fused and unfused quantisation are bit-identical (scale = max|y| / 127,
+// q = rint(y / scale)).
+template <int NCH, bool FULL>
+__device__ __forceinline__ void emit_row(const RowWords& y, int C, int lane, int row, bf16* __restrict__ out,
                                          int8_t* __restrict__ q, float* __restrict__ qscale) {
   if (q == nullptr) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int c = (lane + 64 * i) * 8;
-      if (c < C) {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)y.v[i][j];
-        *reinterpret_cast<bf16x8*>(out + (size_t)row * C + c) = o;
-      }
+      if (in_row<FULL>(c, C))
+        *reinterpret_cast<uint4*>(out + (size_t)row * C + c) = make_uint4(y.w[i][0], y.w[i][1], y.w[i][2], y.w[i][3]);
     }
     return;
   }
   float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
-    if ((lane + 64 * i) * 8 < C) {
+    if (in_row<FULL>((lane + 64 * i) * 8, C)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(y.v[i][j]));
+      for (int j = 0; j < 4; ++j) {
+        f32x2 v = unpack2(y.w[i][j]);
+        mx = fmaxf(mx, fabsf(v.x));
+        mx = fmaxf(mx, fabsf(v.y));
+      }
     }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -84,11 +129,12 @@ __device__ __forceinline__ void emit_row(const RowRegs& y, int C, int lane, int 
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = (lane + 64 * i) * 8;
-    if (c < C) {
+    if (in_row<FULL>(c, C)) {
       unsigned lo = 0, hi = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int a = __float2int_rn(y.v[i][j] * inv), b = __float2int_rn(y.v[i][4 + j] * inv);
+      for (int j = 0; j < 4; ++j) {      // element j of the chunk lives in pair j >> 1; elements 0..3 -> lo, 4..7 -> hi
+        f32x2 va = unpack2(y.w[i][j >> 1]), vb = unpack2(y.w[i][2 + (j >> 1)]);
+        int a = __float2int_rn(((j & 1) ? va.y : va.x) * inv), b = __float2int_rn(((j & 1) ? vb.y : vb.x) * inv);
         a = a < -127 ? -127 : (a > 127 ? 127 : a);
         b = b < -127 ? -127 : (b > 127 ? 127 : b);
         lo |= (unsigned)(a & 0xFF) << (8 * j);
@@ -103,70 +149,71 @@ __device__ __forceinline__ void emit_row(const RowRegs& y, int C, int lane, int 
 // LN (no affine) + per-frame modulation.  Rounding points of the reference (bf16 tensors, causal_model.py:445):
 //   y = bf16(LN(x)); s1 = bf16(1 + bf16(mod_s + e_s)); out = bf16(bf16(y * s1) + bf16(mod_t + e_t))
 // PRE: `e` already holds bf16(mod + e) for every chunk (ll_modulation_table, once per forward for all layers): two vector
-// loads and six VALU operations per element less in a kernel that is as much VALU- as HBM-bound (about 16 operations per element
-// at 4.6 waves per SIMD); the values are the ones the unfused form computes, bit for bit.
-template <int NCH, bool PRE>
+// loads and three operations per element less; the values are the ones the unfused form computes, bit for bit.
+template <int NCH, bool FULL, bool PRE>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
                                                           const bf16* __restrict__ e, const bf16* __restrict__ mod,
                                                           int nmod, int shift_idx, int scale_idx, int rows, int L,
                                                           int C, int frame_len, int F, float eps,
                                                           int8_t* __restrict__ q, float* __restrict__ qscale) {
   int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // one row per wave: the row decode runs on the scalar unit
   if (row >= rows) return;
   RowRegs r;
-  load_row<NCH>(x + (size_t)row * C, C, lane, r);
-  float mean, rstd;
-  layernorm_stats<NCH>(r, C, lane, eps, mean, rstd);
+  load_row<NCH, FULL>(x + (size_t)row * C, C, lane, r);
   int b = row / L, f = (row % L) / frame_len;
   const bf16* eb = e + ((size_t)(b * F + f) * nmod) * C;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    int c = (lane + 64 * i) * 8;
-    if (c < C) {
-      bf16x8 es = *reinterpret_cast<const bf16x8*>(eb + (size_t)scale_idx * C + c);
-      bf16x8 et = *reinterpret_cast<const bf16x8*>(eb + (size_t)shift_idx * C + c);
-      bf16x8 ms, mt;
-      if (!PRE) {
-        ms = *reinterpret_cast<const bf16x8*>(mod + (size_t)scale_idx * C + c);
-        mt = *reinterpret_cast<const bf16x8*>(mod + (size_t)shift_idx * C + c);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float y = rbf((r.v[i][j] - mean) * rstd);
-        float s1 = rbf(1.0f + (PRE ? (float)es[j] : rbf((float)ms[j] + (float)es[j])));
-        float t = PRE ? (float)et[j] : rbf((float)mt[j] + (float)et[j]);
-        r.v[i][j] = rbf(rbf(y * s1) + t);
-      }
-    }
+  RowWords es, et, ms, mt;                               // the modulation chunks travel while the row statistics are reduced
+  load_words<NCH, FULL>(eb + (size_t)scale_idx * C, C, lane, es);
+  load_words<NCH, FULL>(eb + (size_t)shift_idx * C, C, lane, et);
+  if (!PRE) {
+    load_words<NCH, FULL>(mod + (size_t)scale_idx * C, C, lane, ms);
+    load_words<NCH, FULL>(mod + (size_t)shift_idx * C, C, lane, mt);
   }
-  emit_row<NCH>(r, C, lane, row, out, q, qscale);
+  asm volatile("" ::: "memory");                          // (the compiler would sink these loads below the reductions again)
+  __builtin_amdgcn_sched_barrier(0);
+  float rstd;
+  layernorm_center<NCH, FULL>(r, C, lane, eps, rstd);
+  const f32x2 r2 = splat2(rstd), one = splat2(1.0f);
+  RowWords o;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 y = rbf2(r.p[i][j] * r2);
+      f32x2 sc = PRE ? unpack2(es.w[i][j]) : rbf2(unpack2(ms.w[i][j]) + unpack2(es.w[i][j]));
+      f32x2 t = PRE ? unpack2(et.w[i][j]) : rbf2(unpack2(mt.w[i][j]) + unpack2(et.w[i][j]));
+      f32x2 s1 = rbf2(one + sc);
+      o.w[i][j] = pack2(rbf2(y * s1) + t);
+    }
+  emit_row<NCH, FULL>(o, C, lane, row, out, q, qscale);
 }
 
 // LN with affine (norm3): F.layer_norm computes (x-mean)*rstd*w + b in fp32 and rounds once.
-template <int NCH>
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(256) void layernorm_affine_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                                const bf16* __restrict__ bb, bf16* __restrict__ out,
                                                                int rows, int C, float eps, int8_t* __restrict__ q,
                                                                float* __restrict__ qscale) {
   int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // one row per wave: row arithmetic on the scalar unit
   if (row >= rows) return;
   RowRegs r;
-  load_row<NCH>(x + (size_t)row * C, C, lane, r);
-  float mean, rstd;
-  layernorm_stats<NCH>(r, C, lane, eps, mean, rstd);
+  load_row<NCH, FULL>(x + (size_t)row * C, C, lane, r);
+  RowWords wv, bv;
+  load_words<NCH, FULL>(w, C, lane, wv);
+  load_words<NCH, FULL>(bb, C, lane, bv);
+  asm volatile("" ::: "memory");           // every load of the row is in flight before the reductions (see ln_modulate_kernel)
+  __builtin_amdgcn_sched_barrier(0);
+  float rstd;
+  layernorm_center<NCH, FULL>(r, C, lane, eps, rstd);
+  const f32x2 r2 = splat2(rstd);
+  RowWords o;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    int c = (lane + 64 * i) * 8;
-    if (c < C) {
-      bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
-      bf16x8 bv = *reinterpret_cast<const bf16x8*>(bb + c);
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r.v[i][j] = rbf((r.v[i][j] - mean) * rstd * (float)wv[j] + (float)bv[j]);
-    }
-  }
-  emit_row<NCH>(r, C, lane, row, out, q, qscale);
+    for (int j = 0; j < 4; ++j) o.w[i][j] = pack2(r.p[i][j] * r2 * unpack2(wv.w[i][j]) + unpack2(bv.w[i][j]));
+  emit_row<NCH, FULL>(o, C, lane, row, out, q, qscale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -177,29 +224,36 @@ __device__ __forceinline__ float rms_rinv(const RowRegs& r, int C, float eps) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += r.v[i][j] * r.v[i][j];
+    for (int j = 0; j < 4; ++j) {
+      f32x2 xx = r.p[i][j] * r.p[i][j];
+      s += xx.x;
+      s += xx.y;
+    }
   return 1.0f / sqrtf(wave_sum(s) / (float)C + eps);
 }
 
-template <int NCH>
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                       bf16* __restrict__ out, int rows, int C, int ldx, int ldo,
                                                       float eps) {
   int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // one row per wave: row arithmetic on the scalar unit
   if (row >= rows) return;
   RowRegs r;
-  load_row<NCH>(x + (size_t)row * ldx, C, lane, r);
-  float rinv = rms_rinv<NCH>(r, C, eps);
+  load_row<NCH, FULL>(x + (size_t)row * ldx, C, lane, r);
+  RowWords wv;
+  load_words<NCH, FULL>(w, C, lane, wv);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x2 ri = splat2(rms_rinv<NCH>(r, C, eps));
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = (lane + 64 * i) * 8;
-    if (c < C) {
-      bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
-      bf16x8 o;
+    if (in_row<FULL>(c, C)) {
+      unsigned o[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16)(rbf(r.v[i][j] * rinv) * (float)wv[j]);
-      *reinterpret_cast<bf16x8*>(out + (size_t)row * ldo + c) = o;
+      for (int j = 0; j < 4; ++j) o[j] = pack2(rbf2(r.p[i][j] * ri) * unpack2(wv.w[i][j]));
+      *reinterpret_cast<uint4*>(out + (size_t)row * ldo + c) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -209,11 +263,45 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
 // writes roped q to q_out and roped k / raw v straight into their KV-cache slots (no clone / cat / second pass).
 // RoPE pairs are (2i, 2i+1) inside each 128-wide head (causal_model.py:45-55); pair p < nf rotates by the frame
 // angle, the rest by the (h, w) angles; angles come from fp32 (cos, sin) tables made from the fp64 table on the host.
+// (This kernel keeps the scalar one-element form: the pair form of the kernels above -- with the row's loads issued together -- was
+// measured at 22.5 - 24 us against 17.5 us for this one in the model-order replay although it issues a third fewer vector
+// instructions; profiles/r04_row_kernels.md.)
+struct RowF {
+  float v[MAXCH][8];
+};
+
 template <int NCH>
-__device__ __forceinline__ void norm_rope_store(RowRegs& r, const bf16* __restrict__ w, int C, int lane, float eps,
+__device__ __forceinline__ void load_row_f(const bf16* __restrict__ p, int C, int lane, RowF& r) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = (lane + 64 * i) * 8;
+    if (c < C) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(p + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = (float)t[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[i][j] = 0.f;
+    }
+  }
+}
+
+
+template <int NCH>
+__device__ __forceinline__ float rms_rinv_f(const RowF& r, int C, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += r.v[i][j] * r.v[i][j];
+  return 1.0f / sqrtf(wave_sum(s) / (float)C + eps);
+}
+
+template <int NCH>
+__device__ __forceinline__ void norm_rope_store(RowF& r, const bf16* __restrict__ w, int C, int lane, float eps,
                                                 const float2* __restrict__ rf, const float2* __restrict__ rhw, int nf,
                                                 int half_hd, bf16* __restrict__ dst) {
-  float rinv = rms_rinv<NCH>(r, C, eps);
+  float rinv = rms_rinv_f<NCH>(r, C, eps);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = (lane + 64 * i) * 8;
@@ -242,20 +330,20 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(
     bf16* __restrict__ cache_k, bf16* __restrict__ cache_v, int rows, int L, int C, int half_hd, int nf,
     int frame_len, int start_frame, int S, int write_start, int roped_offset, int write_len, float eps) {
   int lane = threadIdx.x & 63;
-  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // one row per wave: the row decode runs on the scalar unit
   if (row >= rows) return;
   int b = row / L, t = row % L;
   int f = t / frame_len + start_frame, sp = t % frame_len;
   const float2* rf = rope_f + (size_t)f * nf;
   const float2* rhw = rope_hw + (size_t)sp * (half_hd - nf);
   const bf16* src = qkv + (size_t)row * 3 * C;
-  RowRegs r;
-  load_row<NCH>(src, C, lane, r);
+  RowF r;
+  load_row_f<NCH>(src, C, lane, r);
   norm_rope_store<NCH>(r, wq, C, lane, eps, rf, rhw, nf, half_hd, q_out + (size_t)row * C);
   int wi = t - roped_offset;
   bool wr = (wi >= 0) && (wi < write_len);
   size_t slot = ((size_t)b * S + write_start + wi) * C;
-  load_row<NCH>(src + C, C, lane, r);
+  load_row_f<NCH>(src + C, C, lane, r);
   norm_rope_store<NCH>(r, wk, C, lane, eps, rf, rhw, nf, half_hd, wr ? cache_k + slot : nullptr);
   if (wr && cache_v != nullptr) {        // cache_v == NULL: the QKV projection's epilogue has already inserted V (ll_gemm_*_qkv)
 #pragma unroll
@@ -406,13 +494,14 @@ __global__ __launch_bounds__(256) void modulation_table_kernel(const bf16* __res
 
 // ===============================================================================================================
 // host launchers
-#define DISPATCH_NCH(C, CALL)                   \
-  do {                                          \
-    int nch_ = ((C) + 511) / 512;               \
-    if (nch_ == 1) { CALL(1); }                 \
-    else if (nch_ == 2) { CALL(2); }            \
-    else if (nch_ == 3) { CALL(3); }            \
-    else { CALL(4); }                           \
+#define DISPATCH_NCH(C, CALL)                                              \
+  do {                                                                     \
+    int nch_ = ((C) + 511) / 512;                                          \
+    bool full_ = ((C) % 512) == 0;                                         \
+    if (nch_ == 1) { if (full_) CALL(1, true); else CALL(1, false); }      \
+    else if (nch_ == 2) { if (full_) CALL(2, true); else CALL(2, false); } \
+    else if (nch_ == 3) { if (full_) CALL(3, true); else CALL(3, false); } \
+    else { if (full_) CALL(4, true); else CALL(4, false); }                \
   } while (0)
 
 static inline bool row_ok(int C) { return C > 0 && C <= 2048 && (C % 8) == 0; }
@@ -426,13 +515,13 @@ static int ln_modulate_launch(const ll_bf16* x, ll_bf16* out, int8_t* q, float* 
   int rows = B * L;
   if (rows == 0) return LL_OK;
   dim3 grid((rows + 3) / 4);
-#define CALL(N)                                                                                                          \
+#define CALL(N, FL)                                                                                                          \
   do {                                                                                                                   \
     if (mod)                                                                                                             \
-      hipLaunchKernelGGL((ln_modulate_kernel<N, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, \
+      hipLaunchKernelGGL((ln_modulate_kernel<N, FL, false>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, \
                          (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps, q, qscale); \
     else                                                                                                                 \
-      hipLaunchKernelGGL((ln_modulate_kernel<N, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,  \
+      hipLaunchKernelGGL((ln_modulate_kernel<N, FL, true>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,  \
                          (const bf16*)e, (const bf16*)mod, nmod, shift_idx, scale_idx, rows, L, C, L / F, F, eps, q, qscale); \
   } while (0)
   DISPATCH_NCH(C, CALL);
@@ -468,8 +557,8 @@ static int layernorm_affine_launch(const ll_bf16* x, const ll_bf16* w, const ll_
   LL_REQUIRE(row_ok(C), "ll_layernorm_affine: C=%d must be a multiple of 8 and <= 2048", C);
   if (rows == 0) return LL_OK;
   dim3 grid((rows + 3) / 4);
-#define CALL(N)                                                                                              \
-  hipLaunchKernelGGL(layernorm_affine_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x,   \
+#define CALL(N, FL)                                                                                              \
+  hipLaunchKernelGGL((layernorm_affine_kernel<N, FL>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x,   \
                      (const bf16*)w, (const bf16*)b, (bf16*)out, rows, C, eps, q, qscale)
   DISPATCH_NCH(C, CALL);
 #undef CALL
@@ -493,8 +582,8 @@ extern "C" int ll_rmsnorm(const ll_bf16* x, const ll_bf16* w, ll_bf16* out, int 
   LL_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldx >= C && ldo >= C, "ll_rmsnorm: bad row strides %d %d", ldx, ldo);
   if (rows == 0) return LL_OK;
   dim3 grid((rows + 3) / 4);
-#define CALL(N)                                                                                                  \
-  hipLaunchKernelGGL(rmsnorm_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)w, \
+#define CALL(N, FL)                                                                                                  \
+  hipLaunchKernelGGL((rmsnorm_kernel<N, FL>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)w, \
                      (bf16*)out, rows, C, ldx, ldo, eps)
   DISPATCH_NCH(C, CALL);
 #undef CALL
@@ -520,8 +609,8 @@ extern "C" int ll_qk_norm_rope_kv_store(const ll_bf16* qkv, const ll_bf16* wq, c
   int c3 = half / 3;
   int nf = half - 2 * c3;
   dim3 grid((rows + 3) / 4);
-#define CALL(N)                                                                                                        \
-  hipLaunchKernelGGL(qk_norm_rope_kv_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv,            \
+#define CALL(N, FL)                                                                                                        \
+  hipLaunchKernelGGL((qk_norm_rope_kv_kernel<N>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv,            \
                      (const bf16*)wq, (const bf16*)wk, (const float2*)rope_f, (const float2*)rope_hw, (bf16*)q_out,    \
                      (bf16*)cache_k, (bf16*)cache_v, rows, L, C, half, nf, frame_len, start_frame, S, write_start,     \
                      roped_offset, write_len, eps)
