@@ -606,6 +606,8 @@ def run_replica(args, rank, world, local_rank, sync):
     pipe = CausalInferencePipeline(_pipe_args(), dev, generator=gen)
     if os.environ.get("LL_OVERLAP") is not None:                       # kernel A/B only: LL_OVERLAP=0 = the one-stream schedule
         pipe.overlap_context = os.environ["LL_OVERLAP"] == "1"
+    if os.environ.get("LL_NOMEMO") == "1":                             # A/B only: untagged timestep tensors = sigma, time embedding and
+        pipe._timestep = lambda value, b, f, device: torch.full([b, f], value, dtype=torch.float32, device=device)   # modulation table every forward
     extra_blocks = 0 if (args.no_extras or rank != 0) else 1           # one more steady-state block for the kernels table
     nblocks = args.warmup + args.steps + extra_blocks
     T = 3 * nblocks

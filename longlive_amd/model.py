@@ -142,6 +142,7 @@ class CausalWanModelHIP(nn.Module):
         self._rope_f = None
         self._rope_hw: Dict[Tuple[int, int], torch.Tensor] = {}
         self._ctx_cache = None
+        self._time_memo: Dict[tuple, tuple] = {}      # (t value, B, F, HIP stream) -> (parameter key, packed key, e, e0, etab): see forward_frames(t_uniform=)
         # nn.Module's recursive load (e.g. WanDiffusionWrapper.load_state_dict, as inference.py:87/94 loads) never calls a
         # child's load_state_dict override, only its _load_from_state_dict -- which runs these hooks.
         self._register_load_state_dict_pre_hook(self._invalidate_derived)
@@ -152,12 +153,14 @@ class CausalWanModelHIP(nn.Module):
         self._rope_f = None
         self._rope_hw = {}
         self._ctx_cache = None
+        self._time_memo = {}
         return super()._apply(fn, *a, **k)
 
     def _invalidate_derived(self, *unused_hook_args):
         """Drop everything derived from the parameters: the fused QKV / int8 copies and the memoised text embedding."""
         self._packed = None
         self._ctx_cache = None
+        self._time_memo = {}
 
     def invalidate_packed(self):
         """Call after writing parameters through `.data` (which bypasses the version counter that `_pack` checks);
@@ -262,6 +265,11 @@ class CausalWanModelHIP(nn.Module):
         e = ops.linear_small(h, self.time_embedding[2].weight, self.time_embedding[2].bias)
         e0 = ops.linear_small(e, self.time_projection[1].weight, self.time_projection[1].bias, act_in=1)
         return e, e0.view(*t.shape, 6, c.dim)
+
+    def _time_param_key(self):
+        ps = (self.time_embedding[0].weight, self.time_embedding[0].bias, self.time_embedding[2].weight, self.time_embedding[2].bias,
+              self.time_projection[1].weight, self.time_projection[1].bias)
+        return tuple((p.data_ptr(), p._version) for p in ps)
 
     def text_embed(self, context: torch.Tensor):
         """[B, text_len, text_dim] -> [B, text_len, C]   (causal_model.py:984-989).  The reference recomputes this
@@ -376,8 +384,12 @@ class CausalWanModelHIP(nn.Module):
     def forward_frames(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, kv_cache: List[dict],
                        crossattn_cache: List[dict], current_start: int = 0,
                        sink_recache_after_switch: bool = False, sigma: Optional[torch.Tensor] = None,
-                       kv_only: bool = False, layer_wait=None, layer_record=None):
+                       kv_only: bool = False, layer_wait=None, layer_record=None, t_uniform: Optional[float] = None):
         """x [B,F,Cin,H,W] (the wrapper's layout); t [B,F]; context [B,text_len,text_dim].
+        t_uniform: the caller KNOWS that every entry of t equals this host value (the pipelines build their timestep tensors from
+        the four denoising steps + the context step): the time embedding, its projection and the modulation table of all layers
+        depend on nothing else, so they are computed once per (value, B, F, HIP stream) and reused while the parameters they
+        were made from are unchanged -- six launches per forward less, same bits.
         Returns the head output [B, L, 4*Cout] (pre-unpatchify), or (flow, x0) in [B,F,C,H,W] when `sigma`
         (float32 [B*F]) is given.  kv_only: the caller discards the output and only wants the KV caches updated (the
         clean-context pass and the recache pass, causal_inference.py:192-200, interactive_causal_inference.py:34-106):
@@ -397,7 +409,6 @@ class CausalWanModelHIP(nn.Module):
         x = x.to(bf16).contiguous()
         pe = self.patch_embedding
         xs = ops.gemm(ops.patchify(x), pe.weight.view(C, -1), pe.bias)                      # [B, L, C]
-        e, e0 = self.time_embed(t)
         need_ctx = any(not cc["is_init"] for cc in crossattn_cache)
         ctx = self.text_embed(context) if need_ctx else None
 
@@ -406,7 +417,21 @@ class CausalWanModelHIP(nn.Module):
         last = len(self.blocks) - 1
         P = self._pack()       # validated against the live parameters once per forward
         premod = self.use_modulation_table
-        etab = ops.modulation_table(e0, self._mods) if premod else None   # [NL, B, F, 6, C] = modulation + e0, one launch
+        memo_key = None
+        if t_uniform is not None and x.is_cuda and tuple(t.shape) == (B, F):
+            memo_key = (float(t_uniform), B, F, premod, torch.cuda.current_stream(x.device).cuda_stream)
+            hit = self._time_memo.get(memo_key)
+            if hit is not None and hit[0] == self._time_param_key() and hit[1] is self._packed_key:
+                e, e0, etab = hit[2:]
+            else:
+                hit = None
+        if memo_key is None or hit is None:
+            e, e0 = self.time_embed(t)
+            etab = ops.modulation_table(e0, self._mods) if premod else None   # [NL, B, F, 6, C] = modulation + e0, one launch
+            if memo_key is not None:
+                if len(self._time_memo) >= 64:       # (a caller sweeping many timestep values: start over rather than grow)
+                    self._time_memo = {}
+                self._time_memo[memo_key] = (self._time_param_key(), self._packed_key, e, e0, etab)
         cur_stream = torch.cuda.current_stream() if (layer_wait is not None or layer_record is not None) else None
         for i in range(len(self.blocks)):
             if layer_wait is not None:

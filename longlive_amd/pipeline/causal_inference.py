@@ -65,6 +65,7 @@ class CausalInferencePipeline(nn.Module):
         self.overlap_decode = False      # inference(): decode each block on a second stream while the next one is generated (same video, bit for bit)
         self._aux = None
         self._ctx_events = None
+        self._timestep_memo = {}
         self._ctx_pending = False
 
     # ------------------------------------------------------------------------------------------------------------
@@ -79,7 +80,18 @@ class CausalInferencePipeline(nn.Module):
         return self.text_encoder(text_prompts=text_prompts)
 
     def _timestep(self, value: float, batch: int, frames: int, device):
-        return torch.full([batch, frames], value, dtype=torch.float32, device=device)
+        """[batch, frames] filled with ONE host value (causal_inference.py:166-170,193 build theirs the same way).  The tensor says
+        so (`_ll_uniform_value`): our wrapper / scheduler then take what depends on the value alone -- sigma, the time embedding and
+        the modulation table of all layers -- from memos instead of seven launches per forward.  One tensor per (value, shape,
+        device, HIP stream), never written to."""
+        dev = torch.device(device)
+        key = (float(value), batch, frames, str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+        t = self._timestep_memo.get(key)
+        if t is None:
+            t = torch.full([batch, frames], value, dtype=torch.float32, device=dev)
+            t._ll_uniform_value = float(value)
+            self._timestep_memo[key] = t
+        return t
 
     def _denoise_block(self, noisy_input, cond, start_frame: int, batch_size: int, nframes: int):
         """4-step denoise + re-noise of one block (causal_inference.py:154-188).  Returns denoised_pred."""
@@ -95,7 +107,7 @@ class CausalInferencePipeline(nn.Module):
             _, denoised = self.generator(noisy_image_or_video=noisy_input, conditional_dict=cond, timestep=timestep,
                                          kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=cs, **kw)
             if index < len(self._step_values) - 1:
-                nxt = self._timestep(self._step_values[index + 1], batch_size * nframes, 1, dev).view(-1)
+                nxt = self._timestep(self._step_values[index + 1], batch_size * nframes, 1, dev)      # [B*F, 1]: add_noise flattens it
                 flat = denoised.flatten(0, 1)
                 noisy_input = self.scheduler.add_noise(flat, self.randn_like(flat), nxt).unflatten(0, denoised.shape[:2])
         return denoised

@@ -27,6 +27,7 @@ class FlowMatchScheduler:
         self.sigmas = self.shift * sig / (1 + (self.shift - 1) * sig)
         self.timesteps = self.sigmas * self.num_train_timesteps
         self._dev = {}
+        self._sigma_memo = {}
 
     def tables(self, device):
         key = str(device)
@@ -35,15 +36,25 @@ class FlowMatchScheduler:
                               self.sigmas.to(device=device, dtype=torch.float32).contiguous())
         return self._dev[key]
 
-    def sigma_of(self, timestep: torch.Tensor) -> torch.Tensor:
-        """sigmas[argmin |timesteps - t|] on the device, float32 [numel]."""
+    def sigma_of(self, timestep: torch.Tensor, uniform_value=None) -> torch.Tensor:
+        """sigmas[argmin |timesteps - t|] on the device, float32 [numel].  uniform_value: the caller knows every entry equals this
+        host value (the pipelines' timestep tensors): the lookup is done once per (value, numel, device, HIP stream)."""
         ts, sg = self.tables(timestep.device)
-        return ops.sigma_lookup(timestep.reshape(-1).to(torch.float32).contiguous(), ts, sg)
+        if uniform_value is None or not timestep.is_cuda:
+            return ops.sigma_lookup(timestep.reshape(-1).to(torch.float32).contiguous(), ts, sg)
+        key = (float(uniform_value), timestep.numel(), str(timestep.device), torch.cuda.current_stream(timestep.device).cuda_stream)
+        hit = self._sigma_memo.get(key)
+        if hit is None:
+            if len(self._sigma_memo) >= 256:
+                self._sigma_memo = {}
+            hit = self._sigma_memo[key] = ops.sigma_lookup(timestep.reshape(-1).to(torch.float32).contiguous(), ts, sg)
+        return hit
 
     def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
         """utils/scheduler.py:159-176: (1 - sigma) * x0 + sigma * noise, per leading index, result in noise.dtype."""
+        uniform = getattr(timestep, "_ll_uniform_value", None)       # (a view of the tensor would not carry the tag)
         if timestep.ndim == 2:
             timestep = timestep.flatten(0, 1)
-        sigma = self.sigma_of(timestep.to(noise.device))
+        sigma = self.sigma_of(timestep.to(noise.device), uniform_value=uniform)
         return ops.add_noise(original_samples.to(torch.bfloat16).contiguous(), noise.to(torch.bfloat16).contiguous(),
                              sigma).type_as(noise)

@@ -60,11 +60,16 @@ class WanDiffusionWrapper(nn.Module):
         dev = self.model.patch_embedding.weight.device
         x = noisy_image_or_video.to(dev)
         t = timestep.to(dev)
-        sigma = self.scheduler.sigma_of(t)                                              # wan_wrapper.py:195-197
-        flow, x0 = self.model.forward_frames(x, t, prompt_embeds.to(dev), kv_cache, crossattn_cache,
-                                             int(current_start or 0), sink_recache_after_switch, sigma=sigma,
-                                             kv_only=kv_only, layer_wait=layer_wait, layer_record=layer_record)
+        # a timestep tensor built by our pipelines from ONE host value says so (pipeline/causal_inference.py::_timestep): what
+        # depends on the value alone -- sigma, time embedding, modulation table -- is then taken from memos
+        t_uniform = getattr(timestep, "_ll_uniform_value", None)
+        sigma = None if kv_only else self.scheduler.sigma_of(t, uniform_value=t_uniform)       # wan_wrapper.py:195-197
+        out = self.model.forward_frames(x, t, prompt_embeds.to(dev), kv_cache, crossattn_cache,
+                                        int(current_start or 0), sink_recache_after_switch, sigma=sigma,
+                                        kv_only=kv_only, layer_wait=layer_wait, layer_record=layer_record,
+                                        t_uniform=t_uniform)
         if kv_only:
             return None, None
+        flow, x0 = out
         dt = noisy_image_or_video.dtype
         return flow.to(dt), x0.to(dt)

@@ -260,6 +260,46 @@ def test_kv_only_context_pass_is_bit_identical():
         assert torch.equal(a, b)
 
 
+def test_timestep_memo_is_bit_identical_and_follows_the_parameters():
+    """The pipelines tag their timestep tensors with the ONE host value they were filled with; sigma, the time embedding and the
+    modulation table of all layers are then taken from memos (wan_wrapper / scheduler / model.forward_frames(t_uniform=)).  Same
+    latents, caches and indices as with untagged tensors (every forward computes them); a change of the time-embedding
+    weights or of a block's modulation must not be served from the memo."""
+    from longlive_amd.pipeline import InteractiveCausalInferencePipeline
+    cfg, gen, enc = _pipe_generator()
+    noise = synth.synth_noise(cfg, 12, seed=45, device=DEV)
+
+    def run(tagged):
+        I = InteractiveCausalInferencePipeline(_pipe_args(False), DEV, generator=gen, text_encoder=enc)
+        I.randn_like = TD.HashRandn(47)
+        if not tagged:
+            I._timestep = lambda value, batch, frames, device: torch.full([batch, frames], value, dtype=torch.float32, device=device)
+        _, lat = I.inference(noise, text_prompts_list=[["p0"], ["p1"]], switch_frame_indices=[6], return_latents=True)
+        torch.cuda.synchronize()
+        return (lat.clone(), [kv["k"].clone() for kv in I.kv_cache1] + [kv["v"].clone() for kv in I.kv_cache1],
+                (I.kv_cache1[0]["global_end_index"], I.kv_cache1[0]["local_end_index"]))
+
+    def same(a, b):
+        return torch.equal(a[0], b[0]) and a[2] == b[2] and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+
+    base = run(False)
+    assert not gen.model._time_memo, "untagged timesteps must not populate the memo"
+    got = run(True)
+    assert gen.model._time_memo and gen.scheduler._sigma_memo
+    assert same(got, base)
+    assert same(run(True), base)                      # second run: served from the memos
+    with torch.no_grad():                             # the parameters move: in-place (version counter) ...
+        gen.model.time_embedding[2].bias.add_(0.25)
+        gen.model.blocks[1].modulation.mul_(1.5)
+    moved_tagged, moved_plain = run(True), run(False)
+    assert same(moved_tagged, moved_plain) and not torch.equal(moved_tagged[0], base[0])
+    sd = {k: v.clone() for k, v in gen.state_dict().items()}      # ... and through load_state_dict
+    sd["model.time_projection.1.bias"] = sd["model.time_projection.1.bias"] + 0.125
+    gen.load_state_dict(sd)
+    assert not gen.model._time_memo
+    assert same(run(True), run(False))
+
+
 def test_two_stream_context_overlap_is_bit_identical():
     """The clean-context pass on the aux stream, one layer ahead of the next block's first forward on the main stream
     (per-layer events), against everything on one stream: same latents, same caches, same indices -- single-prompt stream AND
