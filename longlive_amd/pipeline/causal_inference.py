@@ -13,6 +13,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from ..scheduler import tag_uniform
 from ..wan_wrapper import WanDiffusionWrapper
 
 
@@ -88,8 +89,7 @@ class CausalInferencePipeline(nn.Module):
         key = (float(value), batch, frames, str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
         t = self._timestep_memo.get(key)
         if t is None:
-            t = torch.full([batch, frames], value, dtype=torch.float32, device=dev)
-            t._ll_uniform_value = float(value)
+            t = tag_uniform(torch.full([batch, frames], value, dtype=torch.float32, device=dev), value)
             self._timestep_memo[key] = t
         return t
 

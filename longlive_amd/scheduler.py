@@ -9,6 +9,20 @@ import torch
 from . import ops
 
 
+def tag_uniform(t: torch.Tensor, value: float) -> torch.Tensor:
+    """Mark `t` as filled with the one host value `value` (with the tensor's version counter: an in-place write voids the tag)."""
+    t._ll_uniform_value = (float(value), t._version)
+    return t
+
+
+def uniform_value(t) -> "float | None":
+    """The host value a tensor was tagged with by tag_uniform, or None (untagged, or written to since)."""
+    tag = getattr(t, "_ll_uniform_value", None)
+    if tag is None or tag[1] != t._version:
+        return None
+    return tag[0]
+
+
 class FlowMatchScheduler:
     def __init__(self, shift: float = 5.0, sigma_min: float = 0.0, sigma_max: float = 1.0,
                  num_train_timesteps: int = 1000, num_inference_steps: int = 1000, extra_one_step: bool = True):
@@ -52,7 +66,7 @@ class FlowMatchScheduler:
 
     def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
         """utils/scheduler.py:159-176: (1 - sigma) * x0 + sigma * noise, per leading index, result in noise.dtype."""
-        uniform = getattr(timestep, "_ll_uniform_value", None)       # (a view of the tensor would not carry the tag)
+        uniform = uniform_value(timestep)                            # (a view of the tensor would not carry the tag)
         if timestep.ndim == 2:
             timestep = timestep.flatten(0, 1)
         sigma = self.sigma_of(timestep.to(noise.device), uniform_value=uniform)

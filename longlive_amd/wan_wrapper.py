@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .model import CausalWanModelHIP
-from .scheduler import FlowMatchScheduler
+from .scheduler import FlowMatchScheduler, uniform_value
 from .synth import WanConfig, longlive_1_3b
 
 
@@ -62,7 +62,7 @@ class WanDiffusionWrapper(nn.Module):
         t = timestep.to(dev)
         # a timestep tensor built by our pipelines from ONE host value says so (pipeline/causal_inference.py::_timestep): what
         # depends on the value alone -- sigma, time embedding, modulation table -- is then taken from memos
-        t_uniform = getattr(timestep, "_ll_uniform_value", None)
+        t_uniform = uniform_value(timestep)
         sigma = None if kv_only else self.scheduler.sigma_of(t, uniform_value=t_uniform)       # wan_wrapper.py:195-197
         out = self.model.forward_frames(x, t, prompt_embeds.to(dev), kv_cache, crossattn_cache,
                                         int(current_start or 0), sink_recache_after_switch, sigma=sigma,

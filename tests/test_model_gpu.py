@@ -282,6 +282,11 @@ def test_timestep_memo_is_bit_identical_and_follows_the_parameters():
     def same(a, b):
         return torch.equal(a[0], b[0]) and a[2] == b[2] and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
 
+    from longlive_amd.scheduler import tag_uniform, uniform_value
+    t = tag_uniform(torch.full([1, 3], 5.0, device=DEV), 5.0)
+    assert uniform_value(t) == 5.0 and uniform_value(t.view(-1)) is None
+    t.mul_(2.0)
+    assert uniform_value(t) is None, "an in-place write must void the tag"
     base = run(False)
     assert not gen.model._time_memo, "untagged timesteps must not populate the memo"
     got = run(True)
