@@ -89,3 +89,19 @@ def test_packed_weights_follow_the_parameters():
     m.blocks[0].self_attn.v.weight.data.mul_(3)
     m.invalidate_packed()
     assert torch.equal(m._pack()[0]["wqkv"][2 * cfg.dim:], m.blocks[0].self_attn.v.weight)
+
+
+def test_uniform_timestep_tag_follows_the_tensor():
+    """The pipelines tag their timestep tensors with the host value they were filled with (scheduler.tag_uniform); the tag must
+    not survive anything that can change the values: views are untagged objects, an in-place write bumps the version counter."""
+    from longlive_amd.scheduler import tag_uniform, uniform_value
+    t = tag_uniform(torch.full([2, 3], 750.0), 750.0)
+    assert uniform_value(t) == 750.0
+    assert uniform_value(t.view(-1)) is None and uniform_value(t.clone()) is None and uniform_value(torch.zeros(3)) is None
+    assert uniform_value(t.to("cpu")) == 750.0            # same device: .to() returns the tensor itself
+    t[0, 0] = 1.0
+    assert uniform_value(t) is None
+    pipe = CausalInferencePipeline.__new__(CausalInferencePipeline)
+    pipe._timestep_memo = {}
+    a, b = pipe._timestep(500.0, 1, 3, "cpu"), pipe._timestep(500.0, 1, 3, "cpu")
+    assert a is b and uniform_value(a) == 500.0 and pipe._timestep(500.0, 3, 1, "cpu") is not a
