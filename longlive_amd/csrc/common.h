@@ -21,6 +21,23 @@ __device__ __forceinline__ bf16 f2bf(float f) { return (bf16)f; }
 // round an fp32 value to bf16 precision and come back (the reference's intermediate rounding points)
 __device__ __forceinline__ float rbf(float f) { return (float)((bf16)f); }
 
+// pairs of elements: a 32-bit word of a bf16 row is two values; fp32 steps on pairs compile to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32,
+// a bf16 rounding point is ONE v_cvt_pk_bf16_f32 per pair (+ shift / mask when the value is used again)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ f32x2 unpack2(unsigned u) {
+  f32x2 r;
+  r.x = __builtin_bit_cast(float, u << 16);
+  r.y = __builtin_bit_cast(float, u & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ unsigned pack2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 rbf2(f32x2 v) { return unpack2(pack2(v)); }
+__device__ __forceinline__ f32x2 splat2(float v) {
+  f32x2 r = {v, v};
+  return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

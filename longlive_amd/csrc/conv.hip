@@ -390,6 +390,18 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
 // RMS_norm (+ SiLU) over channels, channels-last rows of C in {96, 192, 384} (wan/modules/vae.py:39-55, 193-197):
 //   n = bf16(||x||_2); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = bf16(silu(y))
 // (the reference's bf16 rounding points).  G lanes per pixel (16 / 32 / 64), 8 channels per lane.
+// x / n for a pair with ONE reciprocal per lane: the steps of the IEEE-correct fp32 division the compiler emits (Newton step on the
+// reciprocal -- done by the caller, once --, q0 = x r, two residual corrections) without its operand pre-scaling, which only acts when
+// an exponent is beyond 2^+-96: the caller takes this path for n in [2^-60, 2^60] (and |x| <= n by construction), else the plain `/`.
+__device__ __forceinline__ f32x2 div_by_shared(f32x2 x, float n, float r1) {
+  const f32x2 nn = splat2(-n), rr = splat2(r1);
+  f32x2 q = x * rr;
+  f32x2 rem = __builtin_elementwise_fma(nn, q, x);
+  q = __builtin_elementwise_fma(rem, rr, q);
+  rem = __builtin_elementwise_fma(nn, q, x);
+  return __builtin_elementwise_fma(rem, rr, q);
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void rms_silu_cl_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
                                                           bf16* __restrict__ out, long long pixels, int C, float sqrt_c,
@@ -399,25 +411,58 @@ __global__ __launch_bounds__(256) void rms_silu_cl_kernel(const bf16* __restrict
   long long pix = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + (lane / G);
   if (pix >= pixels) return;
   const int c = sub * 8;
-  float v[8];
+  // on pairs of channels (common.h): 155 vector instructions per lane instead of 316 -- the kernel was bound by them, not by HBM
+  f32x2 v[4];
+  unsigned gw[4] = {0u, 0u, 0u, 0u};
   float ss = 0.f;
   if (c < C) {
-    bf16x8 t = *reinterpret_cast<const bf16x8*>(x + pix * C + c);
+    uint4 t = *reinterpret_cast<const uint4*>(x + pix * C + c);
+    uint4 g4 = *reinterpret_cast<const uint4*>(gamma + c);
+    gw[0] = g4.x, gw[1] = g4.y, gw[2] = g4.z, gw[3] = g4.w;
+    const unsigned xw[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] = (float)t[j]; ss += v[j] * v[j]; }
+    for (int j = 0; j < 4; ++j) {
+      v[j] = unpack2(xw[j]);
+      f32x2 sq = v[j] * v[j];
+      ss += sq.x;            // element order, as the scalar form
+      ss += sq.y;
+    }
   }
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
   float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
   if (c < C) {
-    bf16x8 gv = *reinterpret_cast<const bf16x8*>(gamma + c);
-    bf16x8 o;
+    const bool tame = n >= 0x1p-60f && n <= 0x1p60f;
+    float r0 = __builtin_amdgcn_rcpf(n);
+    float r1 = __builtin_fmaf(__builtin_fmaf(-n, r0, 1.0f), r0, r0);
+    const f32x2 sc = splat2(sqrt_c), one = splat2(1.0f), nl2e = splat2(-1.4426950408889634f);
+    unsigned o[4];
+    f32x2 q[4];
+    if (tame) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float y = rbf(rbf(rbf(v[j] / n) * sqrt_c) * (float)gv[j]);
-      o[j] = (bf16)(do_silu ? silu(y) : y);
+      for (int j = 0; j < 4; ++j) q[j] = div_by_shared(v[j], n, r1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[j].x = v[j].x / n;
+        q[j].y = v[j].y / n;
+      }
     }
-    *reinterpret_cast<bf16x8*>(out + pix * C + c) = o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x2 y = rbf2(rbf2(rbf2(q[j]) * sc) * unpack2(gw[j]));
+      if (do_silu) {           // silu (common.h): y * rcp(1 + exp2(-log2(e) y))
+        f32x2 e = nl2e * y;
+        e.x = __builtin_amdgcn_exp2f(e.x);
+        e.y = __builtin_amdgcn_exp2f(e.y);
+        e = one + e;
+        e.x = __builtin_amdgcn_rcpf(e.x);
+        e.y = __builtin_amdgcn_rcpf(e.y);
+        y = y * e;
+      }
+      o[j] = pack2(y);
+    }
+    *reinterpret_cast<uint4*>(out + pix * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 

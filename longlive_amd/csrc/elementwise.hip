@@ -13,21 +13,6 @@
 // the fp32 steps are v_pk_mul_f32 / v_pk_add_f32 (two elements per instruction), and every bf16 rounding point of the reference is
 // one v_cvt_pk_bf16_f32 per pair (+ the shift / mask when the value is used again).  Same operations in the same order per element
 // as the scalar form: bit-identical results.
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
-__device__ __forceinline__ f32x2 unpack2(unsigned u) {
-  f32x2 r;
-  r.x = __builtin_bit_cast(float, u << 16);
-  r.y = __builtin_bit_cast(float, u & 0xffff0000u);
-  return r;
-}
-__device__ __forceinline__ unsigned pack2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
-__device__ __forceinline__ f32x2 rbf2(f32x2 v) { return unpack2(pack2(v)); }
-__device__ __forceinline__ f32x2 splat2(float v) {
-  f32x2 r = {v, v};
-  return r;
-}
-
 struct RowRegs {
   f32x2 p[MAXCH][4];      // chunk i of the lane: elements 2j, 2j + 1
 };
