@@ -603,6 +603,8 @@ def run_replica(args, rank, world, local_rank, sync):
         gen.model.use_modulation_table = False
     if os.environ.get("LL_FUSE_V") == "0":
         gen.model.fuse_v_insert = False
+    if os.environ.get("LL_TAB32") == "0":                              # kernel A/B only: LN + modulate from the bf16 table
+        gen.model.use_modulation_f32 = False
     pipe = CausalInferencePipeline(_pipe_args(), dev, generator=gen)
     if os.environ.get("LL_OVERLAP") is not None:                       # kernel A/B only: LL_OVERLAP=0 = the one-stream schedule
         pipe.overlap_context = os.environ["LL_OVERLAP"] == "1"

@@ -86,6 +86,18 @@ int ll_ln_modulate(const ll_bf16* x, ll_bf16* out, const ll_bf16* e, const ll_bf
 int ll_modulation_table(const ll_bf16* e, const ll_bf16* mods, ll_bf16* out, int num_layers, int BF, int nmod, int C,
                         ll_stream stream);
 
+/* The fp32 form of the table for ll_ln_modulate_tab: out[l, bf, i, :] = float(bf16(mods[l, i, :] + e[bf, i, :])), and for the chunks
+ * whose bit is set in one_plus_mask (the scale chunks 1 and 4 of a block's six) float(bf16(1 + that)) -- exactly the `1 + e[1]` the
+ * reference forms per token row (wan/modules/causal_model.py:445,463), once per (layer, frame).  out [num_layers, BF, nmod, C] fp32. */
+int ll_modulation_table_f32(const ll_bf16* e, const ll_bf16* mods, float* out, int num_layers, int BF, int nmod, int C,
+                            unsigned one_plus_mask, ll_stream stream);
+
+/* ll_ln_modulate / ll_ln_modulate_q8 from a layer's slice tab [B*F, nmod, C] of ll_modulation_table_f32 (scale_idx must be a chunk
+ * of its one_plus_mask): out = bf16(bf16(bf16(LN(x)) * tab[scale_idx]) + tab[shift_idx]), the same bits with eight vector
+ * instructions per element pair fewer.  Exactly one of out (bf16 [B, L, C]) and q (int8 [B, L, C] with qscale [B*L]) is non-NULL. */
+int ll_ln_modulate_tab(const ll_bf16* x, ll_bf16* out, int8_t* q, float* qscale, const float* tab, int nmod, int shift_idx,
+                       int scale_idx, int B, int L, int C, int F, float eps, ll_stream stream);
+
 /* out = LayerNorm(x) * w + b  (norm3, wan/modules/causal_model.py:397-399,460; wan/modules/model.py:89-99). */
 int ll_layernorm_affine(const ll_bf16* x, const ll_bf16* w, const ll_bf16* b, ll_bf16* out, int rows, int C,
                         float eps, ll_stream stream);

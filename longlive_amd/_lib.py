@@ -23,6 +23,8 @@ SIGNATURES = {
     "ll_flash_attn_plan": [_i, _i, _i, _i, _i, _i, C.c_char_p, _i],
     "ll_ln_modulate": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_modulation_table": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "ll_modulation_table_f32": [_p, _p, _p, _i, _i, _i, _i, C.c_uint, _p],
+    "ll_ln_modulate_tab": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_layernorm_affine": [_p, _p, _p, _p, _i, _i, _f, _p],
     "ll_ln_modulate_q8": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "ll_layernorm_affine_q8": [_p, _p, _p, _p, _p, _i, _i, _f, _p],

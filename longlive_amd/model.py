@@ -136,6 +136,8 @@ class CausalWanModelHIP(nn.Module):
         self.quant: Optional[str] = None
         self.use_modulation_table = True      # modulation + e0 once per (layer, frame) instead of once per token row (A/B switch)
         self.fuse_v_insert = True             # the QKV projection's epilogue writes V into the KV cache (A/B switch)
+        self.use_modulation_f32 = True        # LN + modulate from the fp32 table (1 + scale, shift: ops.modulation_table_f32) beside the
+                                              # bf16 one the gate epilogues read: same bits, fewer instructions per row (A/B switch)
         self.fuse_cross_qnorm = True          # cross-attention q: RMSNorm statistics from the projection's epilogue, applied in the attention
                                               # kernel's Q prologue (no RMSNorm launch) where both generated kernels cover the call (A/B switch)
         self._packed = None
@@ -294,7 +296,7 @@ class CausalWanModelHIP(nn.Module):
                       cac: dict, F: int, grid_hw: Tuple[int, int], current_start: int,
                       sink_recache_after_switch: bool = False, q_buf: Optional[torch.Tensor] = None,
                       kv_insert_only: bool = False, pk: Optional[dict] = None, premod: bool = False,
-                      cache_done_event=None, co_running: bool = False) -> KVPlan:
+                      cache_done_event=None, co_running: bool = False, tab32: Optional[torch.Tensor] = None) -> KVPlan:
         """CausalWanAttentionBlock.forward (causal_model.py:413-477) for block `i`: updates the residual stream
         xs [B, L, C] IN PLACE (L = F * hp * wp tokens, grid_hw = (hp, wp) tokens per frame) and this layer's KV / cross
         caches, returns the layer's KV plan (the caller commits the end indices after all layers,
@@ -302,7 +304,9 @@ class CausalWanModelHIP(nn.Module):
         not initialised).  kv_insert_only: stop after the K/V insert.  premod: `e0` is this layer's slice of
         ops.modulation_table (modulation already added), as forward_frames passes it.  cache_done_event: recorded on the
         current stream right after this layer's LAST access to its KV cache (the self-attention launch, or the insert when
-        kv_insert_only) -- a forward on another stream may touch the layer's cache from then on."""
+        kv_insert_only) -- a forward on another stream may touch the layer's cache from then on.  tab32: this layer's slice
+        [B, F, 6, C] of ops.modulation_table_f32 (chunks 1 and 4 hold 1 + scale): the two LN + modulate launches read it
+        instead of e0."""
         c = self.cfg
         B, L, C = xs.shape
         Hh, D = c.num_heads, c.head_dim
@@ -326,7 +330,10 @@ class CausalWanModelHIP(nn.Module):
                            sa.max_attention_size, sink_recache_after_switch)
         if plan.roll is not None:          # before the projection: its epilogue writes V into the rolled window
             ops.kv_roll(kvc["k"], kvc["v"], *plan.roll)
-        h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 0, 1, F, c.eps)
+        if tab32 is not None:
+            h1 = ops.ln_modulate_tab(xs, tab32, 0, 1, F, c.eps, q8=q8)
+        else:
+            h1 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 0, 1, F, c.eps)
         if self.fuse_v_insert:             # V third of the projection goes straight into its cache slots (GEMM epilogue)
             if q8:
                 qkv = ops.gemm_qkv_v_insert(None, (pk["q_qkv"], pk["s_qkv"]), pk["bqkv"], kvc["v"], plan.write_start,
@@ -373,7 +380,10 @@ class CausalWanModelHIP(nn.Module):
             atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
         self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
         # --- FFN (causal_model.py:462-468) ---
-        h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 3, 4, F, c.eps)
+        if tab32 is not None:
+            h2 = ops.ln_modulate_tab(xs, tab32, 3, 4, F, c.eps, q8=q8)
+        else:
+            h2 = (ops.ln_modulate_q8 if q8 else ops.ln_modulate)(xs, e0, mod, 3, 4, F, c.eps)
         ff = self._lin(h2, pk, "f1", blk.ffn[0].weight, blk.ffn[0].bias, ops.EPI_BIAS_GELU)
         self._lin(ff, pk, "f2", blk.ffn[2].weight, blk.ffn[2].bias, ops.EPI_BIAS_GATE_RES, out=xs, res=xs, e=e0,
                   mod=mod, gate_idx=5, rows_per_batch=L, frame_len=fs)
@@ -417,21 +427,23 @@ class CausalWanModelHIP(nn.Module):
         last = len(self.blocks) - 1
         P = self._pack()       # validated against the live parameters once per forward
         premod = self.use_modulation_table
+        tab_f32 = premod and self.use_modulation_f32 and x.is_cuda
         memo_key = None
         if t_uniform is not None and x.is_cuda and tuple(t.shape) == (B, F):
-            memo_key = (float(t_uniform), B, F, premod, torch.cuda.current_stream(x.device).cuda_stream)
+            memo_key = (float(t_uniform), B, F, premod, tab_f32, torch.cuda.current_stream(x.device).cuda_stream)
             hit = self._time_memo.get(memo_key)
             if hit is not None and hit[0] == self._time_param_key() and hit[1] is self._packed_key:
-                e, e0, etab = hit[2:]
+                e, e0, etab, etab32 = hit[2:]
             else:
                 hit = None
         if memo_key is None or hit is None:
             e, e0 = self.time_embed(t)
             etab = ops.modulation_table(e0, self._mods) if premod else None   # [NL, B, F, 6, C] = modulation + e0, one launch
+            etab32 = ops.modulation_table_f32(e0, self._mods, 0b010010) if tab_f32 else None     # fp32, chunks 1 and 4 = 1 + scale
             if memo_key is not None:
                 if len(self._time_memo) >= 64:       # (a caller sweeping many timestep values: start over rather than grow)
                     self._time_memo = {}
-                self._time_memo[memo_key] = (self._time_param_key(), self._packed_key, e, e0, etab)
+                self._time_memo[memo_key] = (self._time_param_key(), self._packed_key, e, e0, etab, etab32)
         cur_stream = torch.cuda.current_stream() if (layer_wait is not None or layer_record is not None) else None
         for i in range(len(self.blocks)):
             if layer_wait is not None:
@@ -440,7 +452,7 @@ class CausalWanModelHIP(nn.Module):
                                             current_start, sink_recache_after_switch, q_buf,
                                             kv_insert_only=kv_only and i == last, pk=P[i], premod=premod,
                                             cache_done_event=layer_record[i] if layer_record is not None else None,
-                                            co_running=cur_stream is not None))
+                                            co_running=cur_stream is not None, tab32=etab32[i] if tab_f32 else None))
         # commit end indices once all layers have planned with the old values (causal_model.py:1061-1062, 901-904)
         for kvc, plan in zip(kv_cache, plans):
             _kv_commit(kvc, plan.G_new, plan.E_new)

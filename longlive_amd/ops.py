@@ -118,6 +118,42 @@ def ln_modulate_q8(x, e, mod, shift_idx: int, scale_idx: int, num_frames: int, e
     return q, sc
 
 
+def modulation_table_f32(e, mods, one_plus_mask: int):
+    """The fp32 form for ln_modulate_tab: [NL,B,F,nmod,C] float32 = float(bf16(mods[l] + e)), chunks in one_plus_mask
+    float(bf16(1 + bf16(mods[l] + e))) -- the `1 + e[1]` of causal_model.py:445,463 once per (layer, frame)."""
+    _chk(e, "e"); _chk(mods, "mods")
+    B, F, nmod, Cc = e.shape
+    NL = mods.shape[0]
+    assert mods.shape == (NL, nmod, Cc), (mods.shape, e.shape)
+    out = torch.empty(NL, B, F, nmod, Cc, dtype=torch.float32, device=e.device)
+    lib = _lib.load()
+    _lib.check(lib.ll_modulation_table_f32(e.data_ptr(), mods.data_ptr(), out.data_ptr(), NL, B * F, nmod, Cc, int(one_plus_mask),
+                                           _stream()), "ll_modulation_table_f32")
+    return out
+
+
+def ln_modulate_tab(x, tab, shift_idx: int, scale_idx: int, num_frames: int, eps: float, q8: bool = False, tag: str = "ln_modulate"):
+    """ln_modulate / ln_modulate_q8 from a layer's slice tab [B,F,nmod,C] (float32) of modulation_table_f32, whose scale chunk
+    already holds 1 + scale: same bits.  Returns bf16 [B,L,C], or (int8 [B,L,C], float32 scale [B*L]) when q8."""
+    _chk(x, "x"); _chk(tab, "tab", torch.float32)
+    B, L, Cc = x.shape
+    nmod = tab.shape[2]
+    assert tab.shape == (B, num_frames, nmod, Cc), (tab.shape, (B, num_frames, nmod, Cc))
+    lib = _lib.load()
+    if q8:
+        q = torch.empty(B, L, Cc, dtype=torch.int8, device=x.device)
+        sc = torch.empty(B * L, dtype=torch.float32, device=x.device)
+        out = None
+    else:
+        out = torch.empty_like(x)
+        q = sc = None
+    t0 = _t0(tag)
+    _lib.check(lib.ll_ln_modulate_tab(x.data_ptr(), _ptr(out), _ptr(q), _ptr(sc), tab.data_ptr(), nmod, shift_idx, scale_idx,
+                                      B, L, Cc, num_frames, eps, _stream()), "ll_ln_modulate_tab")
+    _t1(tag, t0, (3.0 if q8 else 4.0) * B * L * Cc)
+    return (q, sc) if q8 else out
+
+
 def modulation_table(e, mods):
     """e [B,F,nmod,C] (per forward), mods [NL,nmod,C] (per layer) -> [NL,B,F,nmod,C] = bf16(mods[l] + e): what every block
     computes as `self.modulation.unsqueeze(1) + e` (causal_model.py:440), for all layers in one launch."""

@@ -65,6 +65,9 @@ def test_no_torch_types_in_the_abi():
     (lambda L: L.ll_gemm_bf16_qkv(0, 0, 1, 0, 128, 384, 128, 128, 384, 1, 1, 128, 64, 60, 0, 10, None), "outside cache"),
     (lambda L: L.ll_gemm_bf16(0, 0, 1, 0, 128, 128, 128, 128, 128, 2, 0, 0, 0, 6, 2, 128, 64, None), "res and e"),
     (lambda L: L.ll_modulation_table(0, 0, 0, 30, 3, 6, 1537, None), "bad shape"),
+    (lambda L: L.ll_modulation_table_f32(0, 0, 0, 30, 3, 6, 1536, 0b1000000, None), "one_plus_mask"),
+    (lambda L: L.ll_ln_modulate_tab(0, 1, 1, 1, 0, 6, 0, 1, 1, 9, 1536, 3, 1e-6, None), "exactly one"),
+    (lambda L: L.ll_ln_modulate_tab(0, 1, 0, 0, 0, 6, 0, 7, 1, 9, 1536, 3, 1e-6, None), "bad mod index"),
     (lambda L: L.ll_conv_cl(0, 1, 1, 1, 0, 1, 2, 16, 32, 96, 96, 2624, 3, 3, 0, 96, None), "null operand"),
     (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 1, 0, None, 0, None), "bias or bias + residual"),
     (lambda L: L.ll_gemm_bf16_ksplit(0, 0, 1, 0, 512, 4096, 4096, 4096, 4096, 3, 0, None, 0, None), "needs res"),

@@ -305,6 +305,27 @@ def test_timestep_memo_is_bit_identical_and_follows_the_parameters():
     assert same(run(True), run(False))
 
 
+def test_fp32_modulation_table_is_bit_identical_in_the_pipeline():
+    """model.use_modulation_f32 (LN + modulate from the fp32 table) against the bf16-table path: same latents and caches, bf16 and int8."""
+    from longlive_amd.pipeline import CausalInferencePipeline
+    cfg, gen, enc = _pipe_generator()
+    noise = synth.synth_noise(cfg, 9, seed=45, device=DEV)
+    for quant in (None, "int8"):
+        gen.model.set_quant(quant)
+        outs = []
+        for flag in (True, False):
+            gen.model.use_modulation_f32 = flag
+            P = CausalInferencePipeline(_pipe_args(), DEV, generator=gen, text_encoder=enc)
+            P.randn_like = TD.HashRandn(47)
+            _, lat = P.inference(noise, ["p0"], return_latents=True)
+            torch.cuda.synchronize()
+            outs.append((lat.clone(), [kv["k"].clone() for kv in P.kv_cache1]))
+        assert torch.equal(outs[0][0], outs[1][0]), quant
+        assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1])), quant
+    gen.model.set_quant(None)
+    gen.model.use_modulation_f32 = True
+
+
 def test_two_stream_context_overlap_is_bit_identical():
     """The clean-context pass on the aux stream, one layer ahead of the next block's first forward on the main stream
     (per-layer events), against everything on one stream: same latents, same caches, same indices -- single-prompt stream AND

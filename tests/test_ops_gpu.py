@@ -358,6 +358,27 @@ def test_modulation_table_paths_are_bit_identical(ops):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,F,fs,C,NL", [(2, 3, 24, 256, 3), (1, 3, 1560, 1536, 2), (1, 2, 35, 1280, 1)])
+def test_modulation_table_f32_and_ln_modulate_tab_are_bit_identical(ops, B, F, fs, C, NL):
+    """The fp32 table (chunks 1 and 4 hold 1 + scale, rounded where the reference rounds) + ll_ln_modulate_tab give the bits of
+    ll_ln_modulate / ll_ln_modulate_q8 on the bf16 table -- production width (all chunks in the row), a ragged width, a small one."""
+    x = hn("tx", (B, F * fs, C), 1.7, 0.3, device=DEV)
+    e = hn("te", (B, F, 6, C), 0.5, device=DEV)
+    mods = hn("tmods", (NL, 6, C), 0.1, device=DEV)
+    tab = ops.modulation_table(e, mods)
+    t32 = ops.modulation_table_f32(e, mods, 0b010010)
+    assert t32.shape == (NL, B, F, 6, C) and t32.dtype == torch.float32
+    want = tab.float()
+    want[:, :, :, [1, 4]] = (1.0 + want[:, :, :, [1, 4]]).to(bf).float()
+    assert torch.equal(t32, want)
+    for l in range(NL):
+        for sh, sc in ((0, 1), (3, 4)):
+            assert torch.equal(ops.ln_modulate_tab(x, t32[l], sh, sc, F, 1e-6), ops.ln_modulate(x, tab[l], None, sh, sc, F, 1e-6))
+            qa, sa = ops.ln_modulate_tab(x, t32[l], sh, sc, F, 1e-6, q8=True)
+            qb, sb = ops.ln_modulate_q8(x, tab[l], None, sh, sc, F, 1e-6)
+            assert torch.equal(qa, qb) and torch.equal(sa, sb)
+
+
 @pytest.mark.parametrize("B,F,hp,wp,H,K,ws,ro,wl", [
     (1, 3, 4, 6, 2, 256, 7, 0, 72),        # all new tokens inserted
     (2, 2, 4, 6, 2, 256, 24, 9, 30),       # batch 2, sink-protected head (roped_offset) and a short window

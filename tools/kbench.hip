@@ -298,9 +298,23 @@ static void bench_layerseq(int layers) {
   // KB_FUSE_QN=0: the three-launch form of cross-attention's q path (projection, RMSNorm, attention) instead of the shipped two
   const bool fuse_qn = !(getenv("KB_FUSE_QN") && atoi(getenv("KB_FUSE_QN")) == 0) && ll_gemm_ssq_planes(L, C, C) == H && ll_flash_attn_qnorm_ok(H, 512);
   float* ssq; CK(hipMalloc(&ssq, (size_t)H * L * 4)); CK(hipMemset(ssq, 0, (size_t)H * L * 4));
+  // KB_TAB32=0: LN + modulate from the bf16 table (ll_ln_modulate) instead of the shipped fp32 one (ll_ln_modulate_tab)
+  const bool tab32 = !(getenv("KB_TAB32") && atoi(getenv("KB_TAB32")) == 0);
+  float* e32; CK(hipMalloc(&e32, (size_t)3 * 6 * C * 4));
+  {
+    std::vector<float> he32((size_t)3 * 6 * C);            // what ll_modulation_table_f32 would make of the bf16 table `e`: the two forms
+    for (int f = 0; f < 3; ++f)                             // of the launch then produce the same h (same data for the kernels behind them)
+      for (int i = 0; i < 6; ++i)
+        for (int c = 0; c < C; ++c) {
+          size_t k = ((size_t)f * 6 + i) * C + c;
+          float v = bf2f(e.h[k]);
+          he32[k] = (i == 1 || i == 4) ? bf2f(f2bf(1.0f + v)) : v;
+        }
+    CK(hipMemcpy(e32, he32.data(), he32.size() * 4, hipMemcpyHostToDevice));
+  }
 #define ON(i) (!(skip & (1u << (i))))
   auto layer = [&]() {
-    if (ON(0)) LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 0, 1, 1, L, C, 3, 1e-6f, s));
+    if (ON(0)) { if (tab32) LL(ll_ln_modulate_tab(xs.d, h.d, nullptr, nullptr, e32, 6, 0, 1, 1, L, C, 3, 1e-6f, s)); else LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 0, 1, 1, L, C, 3, 1e-6f, s)); }
     if (ON(1)) LL(ll_gemm_bf16_qkv(h.d, wqkv.d, bqkv.d, qkv.d, L, 3 * C, C, C, 3 * C, vc.d, 1, L, S, S - L, 0, L, s));
     if (ON(2)) LL(ll_qk_norm_rope_kv_store(qkv.d, nw.d, nw.d, rf, rhw, q.d, kc.d, nullptr, 1, L, C, 128, FS, 12, S, S - L, 0, L, 1e-6f, s));
     if (ON(3)) LL(ll_flash_attn(aq, kc.d, vc.d, ao, 1, aLq, H, C, C, C, (long long)S * C, 0, aS, 0, 0, scale, s));
@@ -315,7 +329,7 @@ static void bench_layerseq(int layers) {
       if (ON(8)) LL(ll_flash_attn(q.d, ck.d, cv.d, att.d, 1, L, H, C, C, C, (long long)512 * C, 0, 512, 0, 0, scale, s));
     }
     if (ON(9)) LL(ll_gemm_bf16(att.d, wco.d, bo.d, xs.d, L, C, C, C, C, LL_EPI_BIAS_RES, xs.d, nullptr, nullptr, 0, 0, 0, 0, s));
-    if (ON(10)) LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 3, 4, 1, L, C, 3, 1e-6f, s));
+    if (ON(10)) { if (tab32) LL(ll_ln_modulate_tab(xs.d, h.d, nullptr, nullptr, e32, 6, 3, 4, 1, L, C, 3, 1e-6f, s)); else LL(ll_ln_modulate(xs.d, h.d, e.d, nullptr, 6, 3, 4, 1, L, C, 3, 1e-6f, s)); }
     if (ON(11)) LL(ll_gemm_bf16(h.d, w1.d, b1.d, ffh.d, L, F1, C, C, F1, LL_EPI_BIAS_GELU, nullptr, nullptr, nullptr, 0, 0, 0, 0, s));
     if (ON(12)) LL(ll_gemm_bf16(ffh.d, w2.d, b2.d, xs.d, L, C, F1, F1, C, LL_EPI_BIAS_GATE_RES, xs.d, e.d, nullptr, 6, 5, L, FS, s));
   };
