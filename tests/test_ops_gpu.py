@@ -26,8 +26,8 @@ def hn(name, shape, scale=1.0, shift=0.0, seed=101, device="cpu"):
     return (synth.hash_normal(seed, name, shape, device=device) * scale + shift).to(bf)
 
 
-@pytest.mark.parametrize("C,F,fs,B", [(1536, 3, 40, 1), (256, 2, 24, 2), (1536, 1, 7, 2)])
-def test_ln_modulate(ops, C, F, fs, B):
+@pytest.mark.parametrize("C,F,fs,B", [(1536, 3, 40, 1), (256, 2, 24, 2), (1536, 1, 7, 2), (2048, 2, 9, 1), (1024, 1, 5, 1), (520, 2, 6, 1), (8, 1, 3, 1)])
+def test_ln_modulate(ops, C, F, fs, B):     # widths: whole 512-column chunks (the template case with every load up front), ragged, one lane
     x = hn("x", (B, F * fs, C), 1.7, 0.3)
     e = hn("e", (B, F, 6, C), 0.5)
     mod = hn("mod", (1, 6, C), 1 / math.sqrt(C))
@@ -38,7 +38,7 @@ def test_ln_modulate(ops, C, F, fs, B):
         assert_bf16_close(got, want, 1, 0.99, f"ln_modulate {sh},{sc}")
 
 
-@pytest.mark.parametrize("C,rows", [(1536, 130), (256, 7)])
+@pytest.mark.parametrize("C,rows", [(1536, 130), (256, 7), (2048, 9), (512, 5), (776, 6), (8, 3)])
 def test_layernorm_affine_and_rmsnorm(ops, C, rows):
     x = hn("x2", (rows, C), 2.0, -0.2)
     w = hn("w", (C,), 0.1, 1.0)
@@ -358,7 +358,7 @@ def test_modulation_table_paths_are_bit_identical(ops):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B,F,fs,C,NL", [(2, 3, 24, 256, 3), (1, 3, 1560, 1536, 2), (1, 2, 35, 1280, 1)])
+@pytest.mark.parametrize("B,F,fs,C,NL", [(2, 3, 24, 256, 3), (1, 3, 1560, 1536, 2), (1, 2, 35, 1280, 1), (1, 1, 5, 2048, 1), (1, 2, 3, 8, 2)])
 def test_modulation_table_f32_and_ln_modulate_tab_are_bit_identical(ops, B, F, fs, C, NL):
     """The fp32 table (chunks 1 and 4 hold 1 + scale, rounded where the reference rounds) + ll_ln_modulate_tab give the bits of
     ll_ln_modulate / ll_ln_modulate_q8 on the bf16 table -- production width (all chunks in the row), a ragged width, a small one."""
