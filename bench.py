@@ -189,6 +189,7 @@ class Telemetry:
             self.want_pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
         except Exception:
             pass
+        self._smi_handle, self._xcd = None, []
         self._smi0 = self._smi(device_index)
 
     @staticmethod
@@ -215,15 +216,27 @@ class Telemetry:
                     except Exception:
                         pass
             m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            self._smi_handle = (amdsmi, h)
             return {k: v for k, v in m.items() if isinstance(v, (int, float)) and ("residency" in k or "throttle" in k or "acc" in k)}
         except Exception as exc:
             return {"error": repr(exc)[:120]}
 
     def _loop(self):
+        n = 0
         while not self._stop.is_set():
             for c in self.cards:
                 c["p"].append(self._read(c["power"]))
                 c["f"].append(self._read(c["freq"]))
+            n += 1
+            if n % 10 == 0 and self._smi_handle is not None:     # every 200 ms: the eight XCDs' own clocks (gpu_metrics current_gfxclks)
+                try:
+                    amdsmi, h = self._smi_handle
+                    clk = [c for c in amdsmi.amdsmi_get_gpu_metrics_info(h).get("current_gfxclks", [])
+                           if isinstance(c, (int, float)) and 0 < c < 60000]
+                    if clk:
+                        self._xcd.append(clk)
+                except Exception:
+                    self._smi_handle = None
             self._stop.wait(self.period)
 
     def start(self):
@@ -258,6 +271,10 @@ class Telemetry:
                                  else "; card chosen by highest draw (no PCI match)"))
             if f:
                 out.update(sclk_mhz_avg=sum(f) / len(f), sclk_mhz_min=min(f))
+        if self._xcd:        # a launch with equal work per CU ends with its slowest XCD: the XCDs of one device hold different clocks
+            n = min(len(x) for x in self._xcd)
+            out["xcd_sclk_mhz_avg"] = [round(sum(x[k] for x in self._xcd) / len(self._xcd), 1) for k in range(n)]
+            out["xcd_samples"] = len(self._xcd)
         s1 = self._smi(device_index)
         if self._smi0 and s1 and "error" not in self._smi0 and "error" not in s1:
             out["gpu_metrics_delta"] = {k: s1[k] - self._smi0[k] for k in s1 if k in self._smi0 and s1[k] != self._smi0[k]}
