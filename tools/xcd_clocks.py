@@ -25,6 +25,9 @@ from longlive_amd.wan_wrapper import WanDiffusionWrapper
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=24)
+    ap.add_argument("--load", default="pipe", choices=["pipe", "gemm", "attn"],
+                    help="pipe: the pipeline's steady state; gemm / attn: ONE kernel looped (FFN1 / self-attention at the production shape) -- "
+                         "the same work on every CU, to tell a property of the device from a property of the pipeline's work distribution")
     a = ap.parse_args()
     import amdsmi
     amdsmi.amdsmi_init()
@@ -56,17 +59,35 @@ def main():
                     samples[i].append(repr(exc)[:80])
             stop.wait(0.05)
 
+    from longlive_amd import ops
+    bf = torch.bfloat16
+    if a.load == "gemm":
+        X = torch.randn(1, 4680, 1536, device=dev).to(bf)
+        W = (torch.randn(8960, 1536, device=dev) * 0.0255).to(bf)
+        bias = torch.zeros(8960, device=dev, dtype=bf)
+        work = lambda: ops.gemm(X, W, bias, ops.EPI_BIAS_GELU)
+        reps = 250 * a.blocks
+    elif a.load == "attn":
+        q = torch.randn(1, 4680, 12, 128, device=dev).to(bf)
+        k = torch.randn(1, 18720, 12, 128, device=dev).to(bf)
+        v = torch.randn(1, 18720, 12, 128, device=dev).to(bf)
+        work = lambda: ops.flash_attn(q, k, v, [(0, 18720)])
+        reps = 70 * a.blocks
     thr = threading.Thread(target=loop, daemon=True)
     thr.start()
     t0 = time.perf_counter()
     with torch.no_grad():
-        for _ in range(a.blocks):
-            next(st)
+        if a.load == "pipe":
+            for _ in range(a.blocks):
+                next(st)
+        else:
+            for _ in range(reps):
+                work()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     stop.set()
     thr.join(timeout=2)
-    out = {"frames_per_s": 12 * a.blocks / dt, "devices": {}}
+    out = {"load": a.load, "seconds": dt, "frames_per_s": 12 * a.blocks / dt if a.load == "pipe" else None, "devices": {}}
     for i, ss in samples.items():
         good = [s for s in ss if isinstance(s, tuple)]
         if not good:
