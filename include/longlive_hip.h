@@ -40,6 +40,11 @@ enum ll_epilogue {
   LL_EPI_BIAS_RES = 3        /* out = res + bf16(acc + bias)                                   causal_model.py:460 */
 };
 
+/* ABI version of this header.  Any change to an existing signature or the removal of an entry point bumps it; the Python binding
+ * (longlive_amd/_lib.py) and any other caller must find ll_version() == LL_ABI_VERSION or refuse the library: a stale .so would
+ * otherwise shift `stream` and the pointers silently.  100 = rounds 1-3; 105 = round 4's removals (workspace arguments of
+ * ll_flash_attn, the split-K hand-off entry points) + round 5. */
+#define LL_ABI_VERSION 105
 int ll_version(void);
 const char* ll_last_error(void);
 /* Development knob for A/B timing of kernel variants (tools/kbench, tools/kenergy, LL_TUNING=key=value,... for bench.py);

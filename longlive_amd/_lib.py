@@ -11,6 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblonglive_hip.so")
 
+ABI_VERSION = 105      # include/longlive_hip.h: LL_ABI_VERSION (tests/test_abi.py holds the two together)
+
 _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 # name -> argtypes (restype is always int unless listed in _RESTYPES); mirrors include/longlive_hip.h 1:1
@@ -86,6 +88,9 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from exc
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.ll_version() != ABI_VERSION:
+        raise RuntimeError(f"{path} has ABI version {lib.ll_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(make -C longlive_amd/csrc); a stale library would misread every argument list")
     _lib = lib
     for kv in filter(None, os.environ.get("LL_TUNING", "").split(",")):   # kernel A/B only, e.g. LL_TUNING=attn_variant=2,conv_halo=0
         k, v = kv.split("=")

@@ -57,5 +57,5 @@ void ll_plan_append_knobs(char* out, int cap) {
   if ((int)n + 12 < cap) snprintf(out + n, (size_t)cap - n, " [generator knobs: %s]", LL_ASM_KNOBS);
 }
 
-extern "C" int ll_version(void) { return 100; }
+extern "C" int ll_version(void) { return LL_ABI_VERSION; }
 extern "C" const char* ll_last_error(void) { return g_err; }

@@ -426,6 +426,123 @@ def gen_real_recache(ns):
     _save("real_recache.pt", rec)
 
 
+CONFIG2_SLOTS = 24            # cache slots sampled per (block, layer, k|v)
+CONFIG2_LAYERS = (0, 14, 29)
+CONFIG2_FULL_STEP_BLOCKS = (0, 4, 6)   # blocks whose three intermediate x0 are stored whole (teacher-forced per step)
+CONFIG2_NSAMPLE = 8192
+
+
+def gen_config2(ns):
+    """BASELINE config 2 exactly, through the REFERENCE's CausalInferencePipeline on CPU in bf16
+    (pipeline/causal_inference.py:56-253): LongLive-1.3B shape (30 layers, 60x104 latents), T = 21 latent frames,
+    denoising_step_list [1000, 750, 500, 250] (warped), num_frame_per_block 3, window 12 / sink 3, context_noise 0:
+    7 blocks x (4 denoise forwards + re-noise + clean-context forward) = 35 forwards; the window fills during blocks
+    0-3 and ROLLS in blocks 4-6, every cache entry written by the model itself.  Re-noise draws come from `_HashRandn`.
+
+    Stored: the 21 latent frames; x0 of every denoise forward (whole for blocks 0 / 4 / 6, a fixed 8192-element sample
+    for the others); after each block's context pass 24 sampled slots of K and V of layers 0 / 14 / 29 + end indices.
+
+    Then config 4's switch at full depth on THAT state: InteractiveCausalInferencePipeline._recache_after_switch
+    (interactive_causal_inference.py:34-106) re-encodes frames 9..20 under a new prompt in ONE 30-layer forward
+    (L = Lk = 18720), with global_sink True (caches kept, sink protected) and False (caches zeroed, sink rewritten):
+    x0 of three frames + 96 sampled slots of K / V of layers 0 / 14 / 29 + end indices."""
+    import copy
+    cfg = synth.longlive_1_3b()
+    fs = cfg.frame_seqlen
+    T, nfb = 21, 3
+    t0 = time.time()
+    sd = synth.synth_state_dict(cfg, seed=0)
+    M = build_ref_model(ns, cfg, sd, fs)
+    del sd
+    wr = build_ref_wrapper(ns, M)
+    print(f"config2 model: {time.time() - t0:.1f}s", flush=True)
+    table = {"p0": synth.synth_prompt_embeds(cfg, seed=1), "p1": synth.synth_prompt_embeds(cfg, seed=2)}
+    args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=nfb,
+                           context_noise=0, global_sink=True)
+    P = ns.causal_inference.CausalInferencePipeline(args, "cpu", generator=wr, text_encoder=_fake_text_encoder(table),
+                                                    vae=_FakeVAE())
+    assert (P.num_transformer_blocks, P.frame_seq_length) == (30, fs)
+    noise = synth.synth_noise(cfg, T, seed=0)
+    S = 12 * fs
+    slots = sample_rows(S, CONFIG2_SLOTS)
+    samp = torch.linspace(0, nfb * 16 * cfg.lat_h * cfg.lat_w - 1, CONFIG2_NSAMPLE).round().long()
+    rec = dict(T=T, steps=[float(t) for t in P.denoising_step_list], slots=slots, sample_idx=samp, layers=list(CONFIG2_LAYERS),
+               renoise_seed=43, noise_seed=0, prompt_seed=1, blocks=[])
+    calls = []
+    orig_fwd = wr.forward
+
+    def spy(*a, **k):
+        t1 = time.time()
+        out = orig_fwd(*a, **k)
+        n = len(calls)
+        blk, j = divmod(n, 5)
+        calls.append(dict(t=float(k["timestep"].flatten()[0]), current_start=int(k["current_start"])))
+        if j == 0:
+            rec["blocks"].append(dict(x0_steps=[], x0_samples=[], flow_std=[]))
+        b = rec["blocks"][blk]
+        if j < 4:
+            x0 = out[1]
+            b["x0_samples"].append(x0.flatten()[samp].clone())
+            b["flow_std"].append(float(out[0].float().std()))
+            if blk in CONFIG2_FULL_STEP_BLOCKS and j < 3:
+                b["x0_steps"].append(x0.clone())
+        else:
+            kv = k["kv_cache"]
+            b["k"] = [kv[l]["k"][0, slots].clone() for l in CONFIG2_LAYERS]
+            b["v"] = [kv[l]["v"][0, slots].clone() for l in CONFIG2_LAYERS]
+            b["idx"] = (int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"]))
+        print(f"  call {n} (block {blk}, {'ctx' if j == 4 else 'step %d' % j}, t={calls[-1]['t']:.0f}): "
+              f"{time.time() - t1:.1f}s", flush=True)
+        return out
+
+    real_randn_like = torch.randn_like
+    wr.forward = spy
+    try:
+        torch.randn_like = _HashRandn(43)
+        t0 = time.time()
+        _, lat = P.inference(noise, ["p0"], return_latents=True)
+        print(f"config2 pipeline (21 frames, {len(calls)} forwards): {time.time() - t0:.1f}s", flush=True)
+    finally:
+        torch.randn_like = real_randn_like
+        wr.forward = orig_fwd
+    assert len(calls) == 35
+    rec["calls"] = calls
+    rec["latents"] = lat.clone()
+    _save("config2_pipe.pt", rec)
+
+    # ---- config 4's switch at full depth, entered from the state the 21-frame run left
+    rslots = sample_rows(S, 96)
+    rr = dict(slots=rslots, frames=[0, 5, 11], layers=list(CONFIG2_LAYERS), start_frame=T, prompt_seed=2)
+    for gs in (True, False):
+        args.global_sink = gs
+        I = ns.interactive.InteractiveCausalInferencePipeline(args, "cpu", generator=wr,
+                                                              text_encoder=_fake_text_encoder(table), vae=_FakeVAE())
+        I.kv_cache1 = copy.deepcopy(P.kv_cache1) if gs else P.kv_cache1     # the second call may consume the original
+        I.crossattn_cache = ref_ca_cache(1, 512, 30, 12, 128)
+        I._set_all_modules_max_attention_size(12)
+        x0s = []
+
+        def spy2(*a, **k):
+            out = orig_fwd(*a, **k)
+            x0s.append(out[1].clone())
+            return out
+        wr.forward = spy2
+        t0 = time.time()
+        try:
+            I._recache_after_switch(lat, T, {"prompt_embeds": table["p1"]})
+        finally:
+            wr.forward = orig_fwd
+        print(f"config2 recache gs={gs}: {time.time() - t0:.1f}s", flush=True)
+        assert len(x0s) == 1 and x0s[0].shape[1] == 12
+        rr[f"gs{int(gs)}"] = dict(x0_frames=x0s[0][:, rr["frames"]].clone(),
+                                  k=[I.kv_cache1[l]["k"][0, rslots].clone() for l in CONFIG2_LAYERS],
+                                  v=[I.kv_cache1[l]["v"][0, rslots].clone() for l in CONFIG2_LAYERS],
+                                  idx=(int(I.kv_cache1[0]["global_end_index"]), int(I.kv_cache1[0]["local_end_index"])))
+        del I
+    _save("config2_recache.pt", rr)
+
+
 def main(argv):
     from oracle import fast_hash
     fast_hash.install()                                # the same integers, ~100x faster on the CPU (host build of csrc/synth_hash.h)

@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
     assert len(decls) >= 15
     for name in decls:
         assert hasattr(lib, name), f"{name} declared in include/longlive_hip.h but not exported"
-    assert lib.ll_version() >= 100
+    want = int(re.search(r"#define\s+LL_ABI_VERSION\s+(\d+)", HEADER).group(1))
+    assert lib.ll_version() == want == _lib.ABI_VERSION      # a stale .so or binding is refused at load (_lib.load)
 
 
 def test_ctypes_table_matches_header():

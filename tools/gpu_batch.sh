@@ -55,7 +55,7 @@ for step in "$@"; do
       echo "pmc_bench rc=$rc"; tail -3 $O/pmc_bench.log | cut -c1-300
       C=$(ls $O/pmc_bench/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$C" ] && python tools/pmc_bench_summary.py $C > $O/pmc_bench.md 2> $O/pmc_bench_summary.err && cat $O/pmc_bench.md | cut -c1-200
       find $O/pmc_bench -name "*.db" -delete 2>/dev/null
-      [ $rc -eq 139 ] && { echo "rocprofv3 --pmc over bench.py crashed again (log kept: $O/pmc_bench.log); not retried"; rc=0; } ;;
+      [ $rc -eq 139 ] && echo "rocprofv3 --pmc over bench.py crashed (log kept: $O/pmc_bench.log); batch stops" ;;
     pmc_inpipe)
       bash tools/pmc_inpipe.sh $O/pmc > $O/pmc.log 2>&1; rc=$?; tail -8 $O/pmc.log
       python tools/pmc_inpipe_summary.py $O/pmc --md $O/pmc_inpipe.md --json $O/pmc_inpipe.json > /dev/null 2> $O/pmc_summary.err; grep "^|" $O/pmc_inpipe.md | cut -c1-220
@@ -68,16 +68,16 @@ for step in "$@"; do
         for e in "" "KB_SKIP=7" "KB_SKIP=2" "KB_SKIP=5" "KB_SKIP=0,10" "KB_SKIP=8" "KB_ATTN_LQ=5376 KB_ATTN_S=17024" "KB_ATTN_LQ=5376 KB_ATTN_S=18752" "KB_SKIP=3"; do
           echo "-- [$e]"; env $e timeout -k 10 120 ./tools/kbench layerseq 900 2>&1 | grep -v "^$"; r=${PIPESTATUS[0]}; dead $r && { rc=$r; break 2; }
         done
-      done | tee $O/layerexp.txt ;;
+      done > >(tee $O/layerexp.txt); wait ;;
     ab)
       a=$(echo "$arg" | cut -d/ -f1); b=$(echo "$arg" | cut -d/ -f2); n=$(echo "$arg" | cut -d/ -f3); n=${n:-2}; rc=0
       for i in $(seq 1 $n); do for t in "$a" "$b"; do
         LL_TUNING=$t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/ab_$i.json 2> $O/ab_$i.err; rc=$?; dead $rc && break 2
         echo -n "[$t] "; benchline $O/ab_$i.json
-      done; done | tee -a $O/ab.txt ;;
+      done; done > >(tee -a $O/ab.txt); wait ;;
     abseq)
       a=$(echo "$arg" | cut -d/ -f1); b=$(echo "$arg" | cut -d/ -f2); rc=0
-      for i in 1 2 3; do for t in "$a" "$b"; do echo -n "[$t] "; LL_TUNING=$t timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break 2; }; done; done | tee -a $O/abseq.txt ;;
+      for i in 1 2 3; do for t in "$a" "$b"; do echo -n "[$t] "; LL_TUNING=$t timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break 2; }; done; done > >(tee -a $O/abseq.txt); wait ;;
     seqtrace)      # per-kernel durations of the layer sequence under timing-only switches: seqtrace="KB_SKIP=0,10"  (kernel trace of tools/kbench layerseq)
       tag=$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_'); rc=0
       env $arg timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/seqtrace_$tag -- ./tools/kbench layerseq 300 > $O/seqtrace_$tag.log 2>&1; rc=$?
@@ -95,27 +95,27 @@ PY
       for i in $(seq 1 $n); do
         echo -n "[shipped] "; timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
         echo -n "[$v] "; env $v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
-      done | tee -a $O/abenv.txt ;;
+      done > >(tee -a $O/abenv.txt); wait ;;
     ablib)         # interleaved A/B of the layer sequence: in-tree library vs a variant built by tools/build_variant.sh (ablib=<name>[/rounds])
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=3; rc=0
       for i in $(seq 1 $n); do
         echo -n "[shipped] "; timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
         echo -n "[$v] "; LD_LIBRARY_PATH=experiments/r04/libs/$v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
-      done | tee -a $O/ablib_$v.txt ;;
+      done > >(tee -a $O/ablib_$v.txt); wait ;;
     abbenchenv)    # interleaved A/B of bench.py under an environment switch: abbenchenv=<ENV=..>[/rounds]
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
       for i in $(seq 1 $n); do for t in "" "$v"; do
         env $t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abe_$i.json 2> $O/abe_$i.err
         rc=$?; dead $rc && break 2
         echo -n "[${t:-shipped}] "; benchline $O/abe_$i.json
-      done; done | tee -a $O/abbenchenv.txt ;;
+      done; done > >(tee -a $O/abbenchenv.txt); wait ;;
     abbench)       # the same with bench.py: abbench=<name>[/rounds]
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
       for i in $(seq 1 $n); do for t in "" "experiments/r04/libs/$v/liblonglive_hip.so"; do
         if [ -z "$t" ]; then timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abb_$i.json 2> $O/abb_$i.err; else LONGLIVE_HIP_LIB=$t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abb_$i.json 2> $O/abb_$i.err; fi
         rc=$?; dead $rc && break 2
         echo -n "[${t:-shipped}] "; benchline $O/abb_$i.json
-      done; done | tee -a $O/abbench_$v.txt ;;
+      done; done > >(tee -a $O/abbench_$v.txt); wait ;;
     kbench)
       timeout -k 10 300 ./tools/kbench $arg 2>&1 | tee -a $O/kbench.txt; rc=${PIPESTATUS[0]} ;;
     configs)
