@@ -293,8 +293,8 @@ class NoSync:
 
     end_barrier = barrier
 
-    def gather(self, frames, elapsed):
-        return [dict(rank=0, frames=frames, elapsed=elapsed)]
+    def gather(self, frames, elapsed, sclk=None, power=None):
+        return [dict(rank=0, frames=frames, elapsed=elapsed, sclk_mhz_avg=sclk, power_w_avg=power)]
 
 
 class GlooSync:
@@ -312,11 +312,15 @@ class GlooSync:
 
     end_barrier = barrier
 
-    def gather(self, frames, elapsed):
-        t = torch.zeros(self.world, 2, dtype=torch.float64)
-        t[self.rank, 0], t[self.rank, 1] = frames, elapsed
+    def gather(self, frames, elapsed, sclk=None, power=None):
+        """Per-rank (frames, elapsed) and the rank's own device clock / power over its timed region: devices of one node differ by
+        3-8 % at identical code, and a scaling curve must be able to tell that spread from a scaling loss."""
+        t = torch.zeros(self.world, 4, dtype=torch.float64)
+        t[self.rank] = torch.tensor([frames, elapsed, -1.0 if sclk is None else sclk, -1.0 if power is None else power], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return [dict(rank=r, frames=float(t[r, 0]), elapsed=float(t[r, 1])) for r in range(self.world)]
+        opt = lambda x: None if x < 0 else float(x)
+        return [dict(rank=r, frames=float(t[r, 0]), elapsed=float(t[r, 1]), sclk_mhz_avg=opt(t[r, 2]), power_w_avg=opt(t[r, 3]))
+                for r in range(self.world)]
 
     def close(self):
         self.dist.destroy_process_group()
@@ -338,8 +342,8 @@ class PipeSync:
     def end_barrier(self):
         pass                 # the parent takes the max over the replicas' own elapsed times
 
-    def gather(self, frames, elapsed):
-        return [dict(rank=self.rank, frames=frames, elapsed=elapsed)]
+    def gather(self, frames, elapsed, sclk=None, power=None):
+        return [dict(rank=self.rank, frames=frames, elapsed=elapsed, sclk_mhz_avg=sclk, power_w_avg=power)]
 
 
 # ---- the measured body -------------------------------------------------------------------------------------------------
@@ -641,7 +645,7 @@ def run_replica(args, rank, world, local_rank, sync):
     ktimer = None
     if not args.no_kernel_timer and rank == 0:
         ktimer = ops.KernelTimer(tags=("flash_attn_self", "flash_attn_self_co"))
-    tele = Telemetry(local_rank) if rank == 0 else None
+    tele = Telemetry(local_rank)               # every replica samples ITS device's clock / power (per_replica_* in the record)
     torch.cuda.synchronize()
     sync.barrier()
     torch.cuda.synchronize()
@@ -663,9 +667,13 @@ def run_replica(args, rank, world, local_rank, sync):
         return res
     if ktimer is not None and "flash_attn_self" in ktimer.records:
         summ_t = ktimer.summary()
-        s = summ_t["flash_attn_self"]                                   # launches of forwards that run ALONE on the device (3 of 5 per block
-        co = summ_t.get("flash_attn_self_co")                           # with the context-pass overlap on; the other 2 co-run: timed apart)
+        alone = summ_t["flash_attn_self"]                               # launches of forwards that run ALONE on the device (3 of 5 per block
+        co = summ_t.get("flash_attn_self_co")                           # with the context-pass overlap on; the other 2 co-run on two streams)
+        n_all = alone["launches"] + (co["launches"] if co else 0)
+        total_ms = alone["total_ms"] + (co["total_ms"] if co else 0.0)
+        s = dict(launches=n_all, avg_ms=total_ms / n_all, total_ms=total_ms, work_per_launch=alone["work_per_launch"])   # ALL launches
         achieved = s["work_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
+        busy_ms = ktimer.union_ms(("flash_attn_self", "flash_attn_self_co"))   # wall time with >= 1 self-attention launch in flight
         traffic, src = None, None
         plan_now = _plan_text(_lib.load().ll_flash_attn_plan, 4680, 12, 1, 18720, 0, 1)
         pmc = os.path.join(ROOT, "profiles", "r04_pmc_inpipe.json")   # counters of the SAME kernel in the pipeline's launch order
@@ -683,13 +691,19 @@ def run_replica(args, rank, world, local_rank, sync):
                            "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_source": src, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
                            "flop_per_launch": s["work_per_launch"],
-                           "share_of_step": (s["total_ms"] + (co["total_ms"] if co else 0.0)) / (1e3 * elapsed),
-                           "co_running": None if not co else {"launches": co["launches"], "avg_us": 1e3 * co["avg_ms"]},
-                           "note": ("context-pass overlap on (the pipeline's default): per block, the clean-context forward and the next "
-                                    "block's first denoising forward run side by side on two HIP streams; `achieved` / `avg_us` are the "
-                                    "launches of the three forwards that run alone, the co-running launches (longer each, shorter "
-                                    "together) are listed under `co_running`; the `kernels` table is taken on one stream")
-                                   if pipe.overlap_context else None}
+                           "share_of_step": busy_ms / (1e3 * elapsed),
+                           "alone": {"launches": alone["launches"], "avg_us": 1e3 * alone["avg_ms"],
+                                     "frac": alone["work_per_launch"] / (alone["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS},
+                           "co_running": None if not co else {"launches": co["launches"], "avg_us": 1e3 * co["avg_ms"],
+                                                              "frac": co["work_per_launch"] / (co["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS},
+                           "note": ("`achieved` / `avg_us` / `frac` are over ALL self-attention launches of the timed region.  Context-pass "
+                                    "overlap on (the pipeline's default): per block, the clean-context forward and the next block's first "
+                                    "denoising forward run side by side on two HIP streams, so 2 of 5 forwards' launches share the device "
+                                    "with another kernel (`co_running`: longer each, shorter together) and 3 of 5 run `alone`; "
+                                    "`share_of_step` = wall time with at least one self-attention launch in flight / elapsed (union of the "
+                                    "event intervals, not the sum); the `kernels` table is taken on one stream")
+                                   if pipe.overlap_context else
+                                   "one HIP stream: `share_of_step` = wall time with a self-attention launch in flight / elapsed"}
     if extra_blocks:
         try:
             pipe.overlap_context = False                               # one stream: per-kernel times without a co-running forward
@@ -724,6 +738,11 @@ def run_replica(args, rank, world, local_rank, sync):
     return res
 
 
+def _clock_power(res) -> dict:
+    t = res.get("telemetry") or {}
+    return dict(sclk_mhz_avg=t.get("sclk_mhz_avg"), power_w_avg=t.get("power_w_avg"))
+
+
 def final_record(args, world, per_replica, res0):
     frames = sum(r["frames"] for r in per_replica)
     elapsed = max(r["elapsed"] for r in per_replica)
@@ -740,7 +759,9 @@ def final_record(args, world, per_replica, res0):
                                 "forward (pipeline default, bit-identical to one stream; LL_OVERLAP=0 = one stream)")
                                if res0.get("overlap_context") else "one HIP stream per replica",
                    "per_replica_fps": [r["frames"] / r["elapsed"] for r in sorted(per_replica, key=lambda r: r["rank"])],
-                   "per_replica_visible_devices": [r.get("visible") for r in sorted(per_replica, key=lambda r: r["rank"])]},
+                   "per_replica_visible_devices": [r.get("visible") for r in sorted(per_replica, key=lambda r: r["rank"])],
+                   "per_replica_sclk_mhz_avg": [r.get("sclk_mhz_avg") for r in sorted(per_replica, key=lambda r: r["rank"])],
+                   "per_replica_power_w_avg": [r.get("power_w_avg") for r in sorted(per_replica, key=lambda r: r["rank"])]},
         "roofline": res0.get("roofline"), "cpu_baseline": res0.get("cpu_baseline"),
         "telemetry": res0.get("telemetry"),
     }
@@ -815,7 +836,8 @@ def launch_replicas(args, argv):
         p.stdin.close()
         if p.wait() != 0:
             fail(f"replica {r} exited with code {p.returncode}")
-    per = [dict(rank=r, frames=res["frames"], elapsed=res["elapsed"], visible=res.get("visible")) for r, res in enumerate(results)]
+    per = [dict(rank=r, frames=res["frames"], elapsed=res["elapsed"], visible=res.get("visible"), **_clock_power(res))
+           for r, res in enumerate(results)]
     print(json.dumps(final_record(args, n, per, results[0])), flush=True)
 
 
@@ -835,7 +857,8 @@ def main(argv=None):
             raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
         sync = GlooSync(rank, world) if world > 1 else NoSync()
         res = run_replica(args, rank, world, local_rank, sync)
-        per = sync.gather(res["frames"], res["elapsed"])
+        cp = _clock_power(res)
+        per = sync.gather(res["frames"], res["elapsed"], cp["sclk_mhz_avg"], cp["power_w_avg"])
         if rank == 0:
             print(json.dumps(final_record(args, world, per, res)), flush=True)
         if world > 1:
@@ -844,7 +867,7 @@ def main(argv=None):
     if args.gpus > 1:
         return launch_replicas(args, argv)
     res = run_replica(args, 0, 1, 0, NoSync())
-    print(json.dumps(final_record(args, 1, [dict(rank=0, frames=res["frames"], elapsed=res["elapsed"])], res)), flush=True)
+    print(json.dumps(final_record(args, 1, [dict(rank=0, frames=res["frames"], elapsed=res["elapsed"], **_clock_power(res))], res)), flush=True)
 
 
 if __name__ == "__main__":

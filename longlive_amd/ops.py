@@ -27,6 +27,8 @@ class KernelTimer:
     def __init__(self, tags=None):
         self.tags = None if tags is None else set(tags)
         self.records = {}          # tag -> [(start_event, end_event, work)]
+        self.base = torch.cuda.Event(enable_timing=True)      # origin of the wall-clock intervals of union_ms()
+        self.base.record()
 
     def begin(self, tag):
         if self.tags is not None and tag not in self.tags:
@@ -50,6 +52,21 @@ class KernelTimer:
             out[tag] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
                             work_per_launch=sum(w for _, _, w in recs) / len(recs))
         return out
+
+
+    def union_ms(self, tags) -> float:
+        """Wall time during which at least one launch of `tags` was in flight (launches on two HIP streams overlap: the sum of
+        their durations counts the shared time twice).  Call after a device sync."""
+        iv = sorted((self.base.elapsed_time(a), self.base.elapsed_time(b)) for t in tags for a, b, _ in self.records.get(t, []))
+        total, cur0, cur1 = 0.0, None, None
+        for a, b in iv:
+            if cur1 is None or a > cur1:
+                if cur1 is not None:
+                    total += cur1 - cur0
+                cur0, cur1 = a, b
+            else:
+                cur1 = max(cur1, b)
+        return total + ((cur1 - cur0) if cur1 is not None else 0.0)
 
 
 timer: Optional[KernelTimer] = None

@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | tuned=<LL_TUNING_TEST spec> | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs | nstreams[=<args>]
+#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs | nstreams[=<args>] | yardstick[=<args>]
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -122,6 +122,13 @@ PY
       timeout -k 10 400 python tools/run_configs.py 240 > $O/configs34.json 2>$O/configs.err; rc=$?; echo "rc=$rc"; head -c 900 $O/configs34.json; echo ;;
     nstreams)      # nstreams[=<extra args>]: N = 1..4 interleaved prompt streams (tools/nstreams.py)
       timeout -k 10 600 python3 tools/nstreams.py $arg > $O/nstreams.json 2> $O/nstreams.err; rc=$?; echo "nstreams rc=$rc"; tail -c 700 $O/nstreams.json; echo ;;
+    yardstick)     # same-device vendor yardstick (torch.mm / addmm / SDPA beside this library, tools/vendor_yardstick.py), then its kernel trace for the vendor kernels' names
+      timeout -k 10 500 python3 tools/vendor_yardstick.py --out $O/yardstick.json ${arg} > /dev/null 2> $O/yardstick.txt; rc=$?; echo "yardstick rc=$rc"; cat $O/yardstick.txt | cut -c1-200
+      if ! dead $rc; then
+        timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ytrace -- python3 tools/vendor_yardstick.py --rounds 1 --iters 20 > /dev/null 2> $O/ytrace.log; r2=$?; echo "yardstick trace rc=$r2"
+        S=$(ls $O/ytrace/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp $S $O/yardstick_kernel_stats.csv && head -40 $S | cut -c1-220
+        rm -f $O/ytrace/*/*kernel_trace.csv $O/ytrace/*/*.db; dead $r2 && rc=$r2
+      fi ;;
     *) echo "unknown step $step"; rc=1 ;;
   esac
   if dead $rc; then echo "step $step died (rc $rc): batch stopped"; exit $rc; fi
