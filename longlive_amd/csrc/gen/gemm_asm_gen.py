@@ -449,12 +449,12 @@ def generate(WN: int, epi: int, prefix: str, i8: bool = False, persistent: bool 
     g.L(f"{prefix}_EPI")
     I("s_nop 15")
     I("s_nop 15")
-    if KN("NO_EPI"):
+    if KN("NO_EPI") and not persistent:
         I("s_waitcnt vmcnt(0)")
         I("s_endpgm")
     if persistent:
         gen_prefetch(g, c, prefix, "A")                # (older than every operation the epilogue issues: its counted waits are unaffected)
-    tail_stores = gen_epilogue(g, c)
+    tail_stores = 0 if KN("NO_EPI") else gen_epilogue(g, c)      # (timing-only: the persistent form keeps its tile walk without the epilogue)
     if persistent:
         g.L(f"{prefix}_NEXT")                          # (also the target of a V tile that stores nothing)
         I(f"s_add_u32 {sreg(S_TILE)}, {sreg(S_TILE)}, {sreg(S_GRID)}")

@@ -1,8 +1,8 @@
 #!/bin/bash
 # tools/build_variant.sh NAME [VAR=VALUE ...] : a second build of the library with generator knobs (ASM_* for the attention kernel,
-# ASM_G_* for the GEMM kernels) into experiments/r04/libs/NAME/liblonglive_hip.so, for interleaved A/Bs on one device:
-#     LD_LIBRARY_PATH=experiments/r04/libs/NAME ./tools/kbench layerseq 1500      (kbench's RUNPATH comes after LD_LIBRARY_PATH)
-#     LONGLIVE_HIP_LIB=experiments/r04/libs/NAME/liblonglive_hip.so python bench.py ...
+# ASM_G_* for the GEMM kernels) into experiments/libs/NAME/liblonglive_hip.so, for interleaved A/Bs on one device:
+#     LD_LIBRARY_PATH=experiments/libs/NAME ./tools/kbench layerseq 1500      (kbench's RUNPATH comes after LD_LIBRARY_PATH)
+#     LONGLIVE_HIP_LIB=experiments/libs/NAME/liblonglive_hip.so python bench.py ...
 # Schedule knobs are recorded in the variant's ll_*_plan strings; timing-only knobs (NO_*: results INVALID) switch the generators to
 # --diag.  The in-tree library is rebuilt WITHOUT knobs before the script returns, whatever happens in between.
 set -e
@@ -16,11 +16,11 @@ flags=""
 case "$*" in *NO_*) flags="--diag" ;; esac
 clean
 make -C longlive_amd/csrc -j8 GENENV="$*" GENFLAGS="$flags" 2>&1 | grep -E " error|lint findings|refused" | grep -v " 0 lint" || true
-mkdir -p experiments/r04/libs/$name
-cp longlive_amd/liblonglive_hip.so experiments/r04/libs/$name/liblonglive_hip.so
+mkdir -p experiments/libs/$name
+cp longlive_amd/liblonglive_hip.so experiments/libs/$name/liblonglive_hip.so
 python3 - <<PY
 import ctypes as C
-lib = C.CDLL("experiments/r04/libs/$name/liblonglive_hip.so")
+lib = C.CDLL("experiments/libs/$name/liblonglive_hip.so")
 b = C.create_string_buffer(400)
 lib.ll_flash_attn_plan(4680, 12, 1, 18720, 0, 1, b, 400)
 print("variant $name:", b.value.decode()[-120:])

@@ -4,7 +4,7 @@
 # writes under gpurun_out/<outdir-name>/; summaries worth keeping are copied to profiles/ by hand.  Steps run in order and are
 # joined so that a timed-out / killed GPU step stops the batch (no further GPU work after a hang).  Steps:
 #   smoke | tests[=<pytest -k expr>] | testfile=<path>[::k] | tuned=<LL_TUNING_TEST spec> | bench | bench_short | trace | pmc_bench | pmc_inpipe
-#   layerseq[=N] | layerexp | seqtrace=<env> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs | nstreams[=<args>] | yardstick[=<args>]
+#   layerseq[=N] | layerexp | seqtrace=<env> | seqtracelib=<variant> | abenv=<ENV=..>[/rounds] | ablib=<variant>[/rounds] | abbench=<variant>[/rounds] | abbenchenv=<ENV=..>[/rounds] | ab=<LL_TUNING a>/<LL_TUNING b>[/rounds] | abseq=<LL_TUNING a>/<LL_TUNING b> | kbench=<args> | configs | nstreams[=<args>] | yardstick[=<args>]
 set -u
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/$1; shift
@@ -90,6 +90,18 @@ for r in rows[:14]:
     print("  %-64.64s calls %5s avg %9.1f us  total %8.1f ms" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
       rm -f $O/seqtrace_$tag/*/*kernel_trace.csv $O/seqtrace_$tag/*/*.db ;;
+    seqtracelib)   # the same under a variant library (tools/build_variant.sh): seqtracelib=<name>  -- timing-only decompositions (floor table)
+      rc=0
+      LD_LIBRARY_PATH=experiments/libs/$arg timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/seqtrace_$arg -- ./tools/kbench layerseq 300 > $O/seqtrace_$arg.log 2>&1; rc=$?
+      grep layerseq $O/seqtrace_$arg.log | tail -1
+      S=$(ls $O/seqtrace_$arg/*/*kernel_stats.csv 2>/dev/null | head -1)
+      [ -n "$S" ] && python3 - "$S" <<'PY' | tee $O/seqtrace_$arg.txt
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print("  %-64.64s calls %5s avg %9.1f us  total %8.1f ms" % (r["Name"], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
+PY
+      rm -f $O/seqtrace_$arg/*/*kernel_trace.csv $O/seqtrace_$arg/*/*.db ;;
     abenv)         # interleaved A/B of the layer sequence under kbench environment switches: abenv=<ENV=..>[/rounds]  (timing-only experiments)
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=3; rc=0
       for i in $(seq 1 $n); do
@@ -100,7 +112,7 @@ PY
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=3; rc=0
       for i in $(seq 1 $n); do
         echo -n "[shipped] "; timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
-        echo -n "[$v] "; LD_LIBRARY_PATH=experiments/r04/libs/$v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
+        echo -n "[$v] "; LD_LIBRARY_PATH=experiments/libs/$v timeout -k 10 120 ./tools/kbench layerseq 1500; r=$?; dead $r && { rc=$r; break; }
       done > >(tee -a $O/ablib_$v.txt); wait ;;
     abbenchenv)    # interleaved A/B of bench.py under an environment switch: abbenchenv=<ENV=..>[/rounds]
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
@@ -111,7 +123,7 @@ PY
       done; done > >(tee -a $O/abbenchenv.txt); wait ;;
     abbench)       # the same with bench.py: abbench=<name>[/rounds]
       v=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$v" ] && n=2; rc=0
-      for i in $(seq 1 $n); do for t in "" "experiments/r04/libs/$v/liblonglive_hip.so"; do
+      for i in $(seq 1 $n); do for t in "" "experiments/libs/$v/liblonglive_hip.so"; do
         if [ -z "$t" ]; then timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abb_$i.json 2> $O/abb_$i.err; else LONGLIVE_HIP_LIB=$t timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/abb_$i.json 2> $O/abb_$i.err; fi
         rc=$?; dead $rc && break 2
         echo -n "[${t:-shipped}] "; benchline $O/abb_$i.json
@@ -129,6 +141,8 @@ PY
         S=$(ls $O/ytrace/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp $S $O/yardstick_kernel_stats.csv && head -40 $S | cut -c1-220
         rm -f $O/ytrace/*/*kernel_trace.csv $O/ytrace/*/*.db; dead $r2 && rc=$r2
       fi ;;
+    stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
+      timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
   esac
   if dead $rc; then echo "step $step died (rc $rc): batch stopped"; exit $rc; fi
