@@ -141,6 +141,15 @@ PY
         S=$(ls $O/ytrace/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp $S $O/yardstick_kernel_stats.csv && head -40 $S | cut -c1-220
         rm -f $O/ytrace/*/*kernel_trace.csv $O/ytrace/*/*.db; dead $r2 && rc=$r2
       fi ;;
+    floor)         # floor=<variant>[,<variant>...]: the five block-linear launches looped alone (tools/kbench gemmx), the shipped library and
+                   # timing-only variant builds (tools/build_variant.sh ... ASM_G_NO_*) interleaved, two rounds; 60 s limit per run; no profiler
+      rc=0
+      for rep in 1 2; do for v in shipped $(echo "$arg" | tr ',' ' '); do for shp in "4680 4608 1536 0" "4680 1536 1536 2" "4680 1536 1536 3" "4680 8960 1536 1" "4680 1536 8960 2"; do
+        echo -n "[$v] "
+        if [ "$v" = shipped ]; then timeout -k 5 60 ./tools/kbench gemmx 400 $shp; r=$?; else LD_LIBRARY_PATH=experiments/libs/$v timeout -k 5 60 ./tools/kbench gemmx 400 $shp; r=$?; fi
+        [ $r -ne 0 ] && echo "(rc $r)"
+        dead $r && { rc=$r; break 3; }
+      done; done; done > >(tee -a $O/floor.txt); wait ;;
     stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
       timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
