@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=4, help="untimed AR blocks (4 fill the 12-frame window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="the per-kernel table of one more steady-state block, but none of the side numbers (extras)")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernels table and the side numbers after the timed region")
     ap.add_argument("--cpu-layers", type=int, default=30, help="layers of one steady-state forward timed on the CPU (30 = the whole forward, ~20 s)")
     ap.add_argument("--workload", choices=["dit", "vae", "t5"], default="dit",
@@ -724,10 +725,11 @@ def run_replica(args, rank, world, local_rank, sync):
             ops.timer = None
             res["kernels"] = {"error": repr(exc)}
         del stream, pipe
-        try:
-            res["extras"] = run_extras(gen, CausalInferencePipeline, InteractiveCausalInferencePipeline, cfg, dev)
-        except Exception as exc:
-            res["extras"] = {"error": repr(exc)}
+        if not args.kernels_only:
+            try:
+                res["extras"] = run_extras(gen, CausalInferencePipeline, InteractiveCausalInferencePipeline, cfg, dev)
+            except Exception as exc:
+                res["extras"] = {"error": repr(exc)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             del gen                                                    # (the GPU model is no longer needed: the host copy of the weights is the oracle's)

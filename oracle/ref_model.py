@@ -61,9 +61,17 @@ class RefModel:
 
     def __init__(self, cfg: RefConfig, sd: Dict[str, Tensor], dtype=torch.bfloat16,
                  frame_seqlen_for_max_attn: int = 1560, lora: Optional[Dict[str, Tuple[Tensor, Tensor]]] = None,
-                 lora_scaling: float = 1.0):
+                 lora_scaling: float = 1.0, quant: Optional[str] = None):
         self.cfg = cfg
         self.dtype = dtype
+        # quant = "int8": BASELINE config 5's arithmetic (the reference ships no INT8 code, reports.md:24,39 -- this restates the
+        # DEFINITION longlive_amd uses, include/longlive_hip.h ll_quantize_rows / ll_gemm_w8a8): the six per-token linears of every
+        # block (self_attn q/k/v/o, cross_attn q/o, ffn.0, ffn.2) run W8A8 -- weights quantised per output channel, activations per
+        # token, symmetric, scale = max|row| / 127 (1 for an all-zero row), q = clamp(rint(x * (1 / scale)), -127, 127), exact
+        # integer accumulation, y = bf16(float(acc) * (sx[m] * sw[n]) + bias), every step in fp32 in that order.
+        assert quant in (None, "int8")
+        self.quant = quant
+        self._wq: Dict[str, Tuple[Tensor, Tensor]] = {}
         # un-merged LoRA adapters {module name: (A [r,in], B [out,r])}: peft's published forward
         #   y = base(x) + lora_B(lora_A(x)) * scaling   (what the reference runs at inference, inference.py:97-130)
         self.lora = {k: (a.to(dtype), b.to(dtype)) for k, (a, b) in (lora or {}).items()}
@@ -77,7 +85,27 @@ class RefModel:
         self.local_attn_size = cfg.local_attn_size
 
     # -- helpers ----------------------------------------------------------------------------
+    @staticmethod
+    def quantize_rows(x: Tensor) -> Tuple[Tensor, Tensor]:
+        """(q float64 holding the int8 values, scale fp32 [rows]) of a [rows, K] tensor."""
+        xf = x.float()
+        mx = xf.abs().amax(dim=-1)
+        sc = torch.where(mx > 0, mx / 127.0, torch.ones_like(mx))
+        inv = (1.0 / sc).unsqueeze(-1)
+        return torch.round(xf * inv).clamp_(-127, 127).double(), sc
+
+    _W8A8 = (".self_attn.q", ".self_attn.k", ".self_attn.v", ".self_attn.o", ".cross_attn.q", ".cross_attn.o", ".ffn.0", ".ffn.2")
+
     def lin(self, x: Tensor, name: str) -> Tensor:
+        if self.quant == "int8" and name.startswith("blocks.") and name.endswith(self._W8A8):
+            assert name not in self.lora
+            if name not in self._wq:
+                self._wq[name] = self.quantize_rows(self.sd[name + ".weight"])
+            wq, sw = self._wq[name]
+            xq, sx = self.quantize_rows(x.reshape(-1, x.shape[-1]).to(self.dtype))
+            acc = (xq @ wq.t()).float()                                  # exact: |acc| < 2^31 << 2^53; then int32 -> fp32 (RN)
+            y = acc * (sx.unsqueeze(1) * sw.unsqueeze(0)) + self.sd[name + ".bias"].float()
+            return y.to(self.dtype).reshape(*x.shape[:-1], -1)
         y = F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"))
         if name in self.lora:
             a, b = self.lora[name]

@@ -265,6 +265,53 @@ def _real_shape_block(kernels):
     assert abs(float(xs.float().mean()) - rec["y_mean"]) < 2e-3 and abs(float(xs.float().std()) / rec["y_std"] - 1) < 2e-3
 
 
+def test_int8_block_vs_int8_oracle():
+    """BASELINE config 5's arithmetic pinned to its DEFINITION, not just to "close to bf16": one real-shape block in steady state
+    (Lk = 18720, roll + insert) with W8A8 linears on the MI355X against the CPU oracle's restatement of the same scheme
+    (oracle/ref_model.py quant="int8": per-token / per-channel symmetric scales, q = rint(x / scale), exact integer sums,
+    y = bf16(float(acc) * (sx * sw) + bias)).  The two differ only where a bf16 flip of an activation moves an int8 step, so the
+    bound is the bf16 block test's (rel-L2 < 6e-3), four times tighter than the int8-vs-bf16 distance of the same block."""
+    from longlive_amd.model import CausalWanModelHIP, _kv_commit
+    from oracle import ref_model as RM
+    cfg = synth.longlive_1_3b(num_layers=1)
+    fs, S = cfg.frame_seqlen, 12 * cfg.frame_seqlen
+    sd = synth.synth_state_dict(cfg, seed=0, device=DEV, layers=[0])
+    m = CausalWanModelHIP(cfg, device=DEV)
+    m.load_state_dict(sd)
+    for mod in m.modules():
+        if hasattr(mod, "max_attention_size"):
+            mod.max_attention_size = S
+    x0 = synth.hash_normal(71, "blk.x", (1, 3 * fs, cfg.dim), device=DEV).to(bf)
+    e0 = (0.3 * synth.hash_normal(71, "blk.e0", (1, 3, 6, cfg.dim), device=DEV)).to(bf)
+    ctx = synth.hash_normal(71, "blk.ctx", (1, cfg.text_len, cfg.dim), device=DEV).to(bf)
+    k, v = _kv_fill(cfg, 0, S)
+    outs = {}
+    for mode in ("int8", None):
+        m.set_quant(mode)
+        xs = x0.clone()
+        kv = dict(k=k.clone(), v=v.clone(), global_end_index=S, local_end_index=S)
+        ca = {"k": torch.zeros(1, 512, 12, 128, dtype=bf, device=DEV), "v": torch.zeros(1, 512, 12, 128, dtype=bf, device=DEV), "is_init": False}
+        plan = m.block_forward(0, xs, e0, ctx, kv, ca, 3, (30, 52), current_start=S)
+        _kv_commit(kv, plan.G_new, plan.E_new)
+        outs[mode] = (xs.cpu(), kv["k"].cpu(), kv["v"].cpu(), (kv["global_end_index"], kv["local_end_index"]))
+    m.set_quant(None)
+    # the oracle, int8 mode, on the host
+    ref = RM.RefModel(RM.RefConfig.from_cfg(cfg), {kk: vv.cpu() for kk, vv in sd.items()}, frame_seqlen_for_max_attn=fs, quant="int8")
+    ref.max_attention_size = S
+    kvr = dict(k=k.cpu().clone(), v=v.cpu().clone(), global_end_index=S, local_end_index=S)
+    car = dict(k=torch.zeros(1, 512, 12, 128, dtype=bf), v=torch.zeros(1, 512, 12, 128, dtype=bf), is_init=False)
+    y, planr = ref.block(x0.cpu(), 0, e0.cpu(), (3, 30, 52), ctx.cpu(), kvr, car, S, False)
+    got, gk, gv, idx = outs["int8"]
+    r, c = rel_l2(got, y), cosine(got, y)
+    r_bf = rel_l2(got, outs[None][0])
+    print(f"int8 block vs int8 oracle: relL2 {r:.2e} cos {c:.6f}  (the same block, int8 vs bf16 on the GPU: {r_bf:.2e})")
+    assert r < 6e-3 and c > 0.9999, (r, c)
+    assert idx == (planr["G_new"], planr["E_new"])
+    sl = torch.linspace(0, S - 1, 64).round().long()
+    assert rel_l2(gk[0, sl], kvr["k"][0, sl]) < 5e-3 and rel_l2(gv[0, sl], kvr["v"][0, sl]) < 5e-3
+    assert r < 0.6 * r_bf, "the int8 path must sit much closer to its own definition than to the bf16 path"
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.skipif(not _have("real_fwd.pt"), reason="golden missing")
 def test_int8_steady_state_vs_reference(real30):

@@ -150,6 +150,13 @@ PY
         [ $r -ne 0 ] && echo "(rc $r)"
         dead $r && { rc=$r; break 3; }
       done; done; done > >(tee -a $O/floor.txt); wait ;;
+    benchq)        # benchq=<LL_TUNING a>/<LL_TUNING b>[/rounds]: INT8 (W8A8) pipeline, interleaved A/B WITH the per-kernel table of each (bench.py --quant int8)
+      a=$(echo "$arg" | cut -d/ -f1); b=$(echo "$arg" | cut -d/ -f2); n=$(echo "$arg" | cut -d/ -f3); n=${n:-2}; rc=0
+      for i in $(seq 1 $n); do for t in "$a" "$b"; do
+        tag=$(echo "$t" | tr -c 'A-Za-z0-9\n' '_')
+        LL_TUNING=$t timeout -k 10 400 python3 bench.py --quant int8 --steps 12 --warmup 4 --no-cpu-baseline --kernels-only > $O/benchq_${tag}_$i.json 2> $O/benchq_${tag}_$i.err; rc=$?; dead $rc && break 2
+        echo -n "[int8 $t] "; benchline $O/benchq_${tag}_$i.json
+      done; done > >(tee -a $O/benchq.txt); wait ;;
     stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
       timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
