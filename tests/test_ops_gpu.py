@@ -305,6 +305,12 @@ def test_int8_quantize_and_w8a8_gemm(ops):
     wq, sw = ops.quantize_rows(w.to(DEV))
     _dequant_check(xq, sx, x, "activation quantisation")
     _dequant_check(wq, sw, w, "weight quantisation")
+    # the CPU oracle's restatement of the scheme (oracle/ref_model.py RefModel.quantize_rows / lin with quant="int8"): identical
+    # codes and scales on identical inputs, bit for bit
+    from oracle.ref_model import RefModel
+    for t, tq, ts in ((x, xq, sx), (w, wq, sw)):
+        oq, osc = RefModel.quantize_rows(t)
+        assert torch.equal(tq.cpu().double(), oq) and torch.equal(ts.cpu(), osc)
     got = ops.gemm_w8a8(xq, sx, wq, sw, b.to(DEV)).cpu()
     # exact integer reference of the same quantised operands
     acc = xq.cpu().to(torch.int64) @ wq.cpu().to(torch.int64).t()
