@@ -105,3 +105,25 @@ def test_uniform_timestep_tag_follows_the_tensor():
     pipe._timestep_memo = {}
     a, b = pipe._timestep(500.0, 1, 3, "cpu"), pipe._timestep(500.0, 1, 3, "cpu")
     assert a is b and uniform_value(a) == 500.0 and pipe._timestep(500.0, 3, 1, "cpu") is not a
+
+
+def test_kernel_timer_union_counts_overlapping_launches_once():
+    """bench.py's `share_of_step`: launches on two HIP streams overlap; the wall time with at least one of them in flight is the
+    union of their event intervals, not the sum of their durations (ops.KernelTimer.union_ms)."""
+    from longlive_amd import ops
+
+    class Ev:                                   # a recorded event = a point on one clock
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    kt = ops.KernelTimer.__new__(ops.KernelTimer)
+    kt.tags, kt.base = None, Ev(100.0)
+    kt.records = {"a": [(Ev(101.0), Ev(103.0), 1.0), (Ev(110.0), Ev(112.0), 1.0)],        # alone: 2 + 2
+                  "b": [(Ev(102.0), Ev(104.5), 1.0), (Ev(111.0), Ev(111.5), 1.0),        # overlaps the first, inside the second
+                        (Ev(120.0), Ev(121.0), 1.0)]}
+    assert abs(kt.union_ms(("a", "b")) - (3.5 + 2.0 + 1.0)) < 1e-9
+    assert abs(kt.union_ms(("a",)) - 4.0) < 1e-9
+    assert kt.union_ms(("missing",)) == 0.0
