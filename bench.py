@@ -702,7 +702,9 @@ def run_replica(args, rank, world, local_rank, sync):
                                     "denoising forward run side by side on two HIP streams, so 2 of 5 forwards' launches share the device "
                                     "with another kernel (`co_running`: longer each, shorter together) and 3 of 5 run `alone`; "
                                     "`share_of_step` = wall time with at least one self-attention launch in flight / elapsed (union of the "
-                                    "event intervals, not the sum); the `kernels` table is taken on one stream")
+                                    "event intervals, not the sum); HIP events around a launch that shares the device include the time its workgroups waited "
+                                    "for CUs held by the other stream's kernel (an upper bound of its duration: the kernel trace of the same command, "
+                                    "profiles/rNN_kernel_summary.md, has begin -> end of every launch); the `kernels` table is taken on one stream")
                                    if pipe.overlap_context else
                                    "one HIP stream: `share_of_step` = wall time with a self-attention launch in flight / elapsed"}
     if extra_blocks:
