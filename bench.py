@@ -688,11 +688,23 @@ def run_replica(args, rank, world, local_rank, sync):
                        "their own profiled passes: tools/gpu_batch.sh pmc_inpipe; MFMA utilisation over bench.py itself: pmc_bench)")
             except Exception:
                 traffic = None
+        trace_us, trace_src = None, None                       # the kernel trace of the same command, committed (begin -> end of every launch)
+        try:
+            tp = os.path.join(ROOT, "profiles", "r05_kernel_summary.md")
+            for line in open(tp):
+                if "flash_attn_asm_kernel" in line and "(self" in line:
+                    trace_us = float(line.split("|")[3])
+                    trace_src = ("profiles/r05_kernel_summary.md: rocprofv3 --kernel-trace of `bench.py --steps 3 --warmup 4` (tools/gpu_batch.sh trace), "
+                                 "all self-attention launches of its steady-state window; a committed figure, NOT collected in this run")
+                    break
+        except Exception:
+            trace_us = None
         res["roofline"] = {"bound": "mfma", "kernel": plan_now + "; self-attention Lq=4680, Lk=18720, 12 heads", "achieved": achieved,
                            "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_source": src, "launches": s["launches"], "avg_us": 1e3 * s["avg_ms"],
                            "flop_per_launch": s["work_per_launch"],
                            "share_of_step": busy_ms / (1e3 * elapsed),
+                           "kernel_trace_avg_us": trace_us, "kernel_trace_source": trace_src,
                            "alone": {"launches": alone["launches"], "avg_us": 1e3 * alone["avg_ms"],
                                      "frac": alone["work_per_launch"] / (alone["avg_ms"] * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS},
                            "co_running": None if not co else {"launches": co["launches"], "avg_us": 1e3 * co["avg_ms"],
