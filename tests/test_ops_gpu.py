@@ -707,3 +707,23 @@ def test_cross_q_fusion_entry_points_refuse_uncovered_shapes(ops):
     w = hn("rw", (136, 256)).to(DEV)
     with pytest.raises(RuntimeError):
         ops.gemm_ssq(x, w, hn("rb", (136,)).to(DEV))
+
+
+@pytest.mark.parametrize("K", [8, 1032, 2048, 2056, 8960, 9216, 9224])
+def test_quantize_rows_every_kernel_form_equals_the_oracle(ops, K):
+    """ll_quantize_rows keeps rows of up to 9216 elements in registers between the maximum and the rounding pass (4 or 18 chunks of
+    16 bytes per lane) and falls back to the two-pass kernel beyond: all three forms give the oracle's codes and scales bit for bit,
+    incl. ragged last chunks, an all-zero row and a row stride larger than K."""
+    from oracle.ref_model import RefModel
+    rows, ld = 37, K + 16
+    x = hn(f"qr{K}", (rows, ld), 2.0)
+    x[5] = 0
+    x[11, : K] *= 40.0
+    xd = x.to(DEV)
+    q = torch.empty(rows, K, dtype=torch.int8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    from longlive_amd import _lib
+    _lib.check(_lib.load().ll_quantize_rows(xd.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, K, ld, torch.cuda.current_stream().cuda_stream),
+               "ll_quantize_rows")
+    oq, osc = RefModel.quantize_rows(x[:, :K])
+    assert torch.equal(q.cpu().double(), oq) and torch.equal(sc.cpu(), osc)
