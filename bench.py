@@ -363,17 +363,19 @@ def _plan_text(fn, *a):
 
 
 def kernel_table(summary, quant, mod_table=True, fuse_qn=True):
-    """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac)."""
+    """ops.KernelTimer summary of one steady-state block -> rows of (kernel, launches, avg us, work, achieved, peak, frac).
+    Kernel names: the launch plan the library reports for the call (ll_gemm_plan_epi / ll_flash_attn_plan); the two entry points with
+    exactly one kernel behind them (ll_gemm_bf16_ssq, ll_flash_attn_qnorm) are timed under their own tags by the model, so the name
+    follows from the entry point that WAS called, not from a predicate re-evaluated here."""
     from longlive_amd import _lib
     lib = _lib.load()
     i8 = 1 if quant == "int8" else 0
     L, C, F1, LK = 4680, 1536, 8960, 18720
-    fused_qn = bool(fuse_qn and not i8 and lib.ll_gemm_ssq_planes(L, C, C) == 12 and lib.ll_flash_attn_qnorm_ok(12, 512))
-    gemm_shapes = {"gemm_qkv": (L, 3 * C, C), "gemm_o": (L, C, C), "gemm_cq": (L, C, C), "gemm_co": (L, C, C),
+    gemm_shapes = {"gemm_qkv": (L, 3 * C, C), "gemm_o": (L, C, C), "gemm_cq": (L, C, C), "gemm_cq_ssq": (L, C, C), "gemm_co": (L, C, C),
                    "gemm_f1": (L, F1, C), "gemm_f2": (L, C, F1)}
-    what = {"gemm_qkv": "self-attn QKV", "gemm_o": "self-attn O + gate-residual", "gemm_cq": "cross-attn Q",
+    what = {"gemm_qkv": "self-attn QKV", "gemm_o": "self-attn O + gate-residual", "gemm_cq": "cross-attn Q", "gemm_cq_ssq": "cross-attn Q + row sums of squares (the q RMSNorm's statistics)",
             "gemm_co": "cross-attn O + residual", "gemm_f1": "FFN1 + GELU", "gemm_f2": "FFN2 + gate-residual",
-            "flash_attn_self": "self-attention (sink + window from the KV cache)", "flash_attn_cross": "cross-attention (512 text keys)",
+            "flash_attn_self": "self-attention (sink + window from the KV cache)", "flash_attn_cross": "cross-attention (512 text keys)", "flash_attn_cross_qn": "cross-attention (512 text keys), q RMSNorm in its prologue",
             "ln_modulate": "LayerNorm + modulate (norm1 / norm2 / head)", "layernorm_affine": "norm3",
             "rmsnorm": "cross-attn q RMSNorm", "qk_norm_rope_kv_store": "q/k RMSNorm + RoPE + KV insert",
             "kv_roll": "KV window roll", "quantize_rows": "per-token int8 quantisation", "gemm": "embeddings / head GEMMs"}
@@ -381,23 +383,24 @@ def kernel_table(summary, quant, mod_table=True, fuse_qn=True):
     for tag, s in sorted(summary.items(), key=lambda kv: -kv[1]["total_ms"]):
         mfma = tag.startswith("gemm") or tag.startswith("flash_attn")
         if tag in gemm_shapes:
-            epi = {"gemm_qkv": 0, "gemm_o": 2, "gemm_cq": 0, "gemm_co": 3, "gemm_f1": 1, "gemm_f2": 2}[tag]      # LL_EPI_* of the call
+            epi = {"gemm_qkv": 0, "gemm_o": 2, "gemm_cq": 0, "gemm_cq_ssq": 0, "gemm_co": 3, "gemm_f1": 1, "gemm_f2": 2}[tag]      # LL_EPI_* of the call
             # plain: 2 = the fused QKV call (V redirect), 1 = an ordinary call, 0 = a per-batch modulation vector rides along
             # (gate-residual calls when the model runs with use_modulation_table = False: those take the HIP kernels)
             plain = 2 if tag == "gemm_qkv" else (0 if (epi == 2 and not mod_table) else 1)
-            name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, plain)
-            if tag == "gemm_cq" and fused_qn:                       # the projection whose epilogue also leaves the RMSNorm's row sums of squares
-                name = name.replace("gemm_asm_128_bias<", "gemm_asm_128_bias_ssq<")
+            if tag == "gemm_cq_ssq":                                # ll_gemm_bf16_ssq has one kernel (gemm_asm.hip: gemm_asm_ssq_launch)
+                name = "gemm_asm_128_bias_ssq<bf16> tile 256x128 (4 waves x 64 rows, one wave per SIMD, generated schedule), 228 workgroups"
+            else:
+                name = _plan_text(lib.ll_gemm_plan_epi, *gemm_shapes[tag], i8, epi, plain)
         elif tag == "flash_attn_self":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, LK, 0, 1)
         elif tag == "flash_attn_cross":
             name = _plan_text(lib.ll_flash_attn_plan, L, 12, 1, 512, 0, 1)
-            if fused_qn:                                            # the form whose Q prologue applies the q RMSNorm (no rmsnorm launch)
-                name = name.replace("flash_attn_asm_kernel", "flash_attn_asm_qn_kernel")
+        elif tag == "flash_attn_cross_qn":                          # ll_flash_attn_qnorm has one kernel (attention_asm.hip)
+            name = "flash_attn_asm_qn_kernel (4 waves x 64 rows, one wave per SIMD, generated schedule; WanRMSNorm of q in the Q prologue), 228 workgroups"
         else:
             name = {"ln_modulate": "ln_modulate_kernel", "layernorm_affine": "layernorm_affine_kernel", "rmsnorm": "rmsnorm_kernel",
                     "qk_norm_rope_kv_store": "qk_norm_rope_kv_kernel", "kv_roll": "copy_rows_kernel",
-                    "quantize_rows": "quantize_rows_kernel"}.get(tag, tag)
+                    "quantize_rows": "quantize_rows_reg_kernel<4 | 18>"}.get(tag, tag)
         secs = s["avg_ms"] * 1e-3
         if mfma:
             peak = MFMA_I8_DENSE_PEAK_TOPS if (i8 and tag in gemm_shapes) else MFMA_BF16_DENSE_PEAK_TFLOPS

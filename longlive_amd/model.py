@@ -363,7 +363,7 @@ class CausalWanModelHIP(nn.Module):
         xn = (ops.layernorm_affine_q8 if q8 else ops.layernorm_affine)(xs, blk.norm3.weight, blk.norm3.bias, c.eps)
         fuse_qn = (self.fuse_cross_qnorm and not q8 and ops.gemm_ssq_planes(B * L, C, C) == Hh and ops.flash_attn_qnorm_ok(Hh, c.text_len))
         if fuse_qn:
-            qraw, ssq = ops.gemm_ssq(xn, ca.q.weight, ca.q.bias, tag="gemm_cq")
+            qraw, ssq = ops.gemm_ssq(xn, ca.q.weight, ca.q.bias, tag="gemm_cq_ssq")
         else:
             qc = ops.rmsnorm(self._lin(xn, pk, "cq", ca.q.weight, ca.q.bias), ca.norm_q.weight, c.eps)
         if not cac["is_init"]:
@@ -375,7 +375,7 @@ class CausalWanModelHIP(nn.Module):
             ops.gemm(ctx, ca.v.weight, ca.v.bias, out=cac["v"].view(B, c.text_len, C))
             cac["is_init"] = True
         if fuse_qn:
-            atc = ops.flash_attn_qnorm(qraw.view(B, L, Hh, D), ssq, ca.norm_q.weight, c.eps, cac["k"], cac["v"], c.text_len, tag="flash_attn_cross")
+            atc = ops.flash_attn_qnorm(qraw.view(B, L, Hh, D), ssq, ca.norm_q.weight, c.eps, cac["k"], cac["v"], c.text_len, tag="flash_attn_cross_qn")
         else:
             atc = ops.flash_attn(qc.view(B, L, Hh, D), cac["k"], cac["v"], [(0, c.text_len)], tag="flash_attn_cross")
         self._lin(atc.view(B, L, C), pk, "co", ca.o.weight, ca.o.bias, ops.EPI_BIAS_RES, out=xs, res=xs)
