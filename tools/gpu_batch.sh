@@ -157,6 +157,23 @@ PY
         LL_TUNING=$t timeout -k 10 400 python3 bench.py --quant int8 --steps 12 --warmup 4 --no-cpu-baseline --kernels-only > $O/benchq_${tag}_$i.json 2> $O/benchq_${tag}_$i.err; rc=$?; dead $rc && break 2
         echo -n "[int8 $t] "; benchline $O/benchq_${tag}_$i.json
       done; done > >(tee -a $O/benchq.txt); wait ;;
+    clockmatrix)   # clockmatrix[=<variant>,<variant>...]: one kernel looped alone per load with clock / power / energy (tools/clock_matrix.py); the shipped
+                   # library over every load, then each timing-only variant library over the generated GEMM loads
+      rc=0
+      timeout -k 10 200 python3 tools/clock_matrix.py > $O/clock_matrix.jsonl 2> $O/clock_matrix.err; rc=$?; echo "clockmatrix rc=$rc"
+      if ! dead $rc; then for v in $(echo "$arg" | tr ',' ' '); do
+        LONGLIVE_HIP_LIB=experiments/libs/$v/liblonglive_hip.so timeout -k 10 120 python3 tools/clock_matrix.py --loads ffn1,ffn2,qkv >> $O/clock_matrix.jsonl 2>> $O/clock_matrix.err; r=$?
+        dead $r && { rc=$r; break; }
+      done; fi
+      python3 - $O/clock_matrix.jsonl <<'PY'
+import json, sys
+for line in open(sys.argv[1]):
+    try: r = json.loads(line)
+    except Exception: continue
+    x = r.get("xcd_sclk_mhz_avg") or []
+    print("%-12s %-12s %8.1f us %7s TF/s  sclk %6.0f MHz (xcd %s)  %6.0f W  ppt %.2f  %7.2f mJ/launch" % (r["lib"].split("/")[-2] if "/" in r["lib"] else r["lib"], r["load"], r["us_per_launch"], r["tflops"], r["sclk_mhz_avg"] or 0, ("%.0f-%.0f" % (min(x), max(x))) if x else "-", r["power_w_avg"] or 0, r["ppt_residency"] or 0, r["energy_mj_per_launch"]))
+PY
+      ;;
     stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
       timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
