@@ -43,8 +43,8 @@ enum ll_epilogue {
 /* ABI version of this header.  Any change to an existing signature or the removal of an entry point bumps it; the Python binding
  * (longlive_amd/_lib.py) and any other caller must find ll_version() == LL_ABI_VERSION or refuse the library: a stale .so would
  * otherwise shift `stream` and the pointers silently.  100 = rounds 1-3; 105 = round 4's removals (workspace arguments of
- * ll_flash_attn, the split-K hand-off entry points) + round 5. */
-#define LL_ABI_VERSION 105
+ * ll_flash_attn, the split-K hand-off entry points); 106 = round 5 (ll_conv_cl_rms added). */
+#define LL_ABI_VERSION 106
 int ll_version(void);
 const char* ll_last_error(void);
 /* Development knob for A/B timing of kernel variants (tools/kbench, tools/kenergy, LL_TUNING=key=value,... for bench.py);
@@ -269,6 +269,15 @@ int ll_synth_hash(float* out, long long lo, long long n, unsigned long long stre
 int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
                ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample, int ldo,
                ll_stream stream);
+/* ll_conv_cl whose epilogue also applies the RMS_norm (+ SiLU) the decoder runs on that tensor next (ResidualBlock: conv -> RMS_norm
+ * -> SiLU -> conv, wan/modules/vae.py:193-220; rounding points of ll_rms_silu_cl): out_rms [pixels, Cout] = rms_silu(out), written by
+ * the same launch; `out` (the un-normalised tensor, with the residual when `res`) may be NULL when nothing else reads it.  Only for
+ * convolutions whose workgroup holds every channel of a pixel -- ll_conv_cl_rms_ok(...) = 1: the halo-tile kernel with Cout = 96 (the
+ * 480x832 stage, 70 % of the decoder's FLOPs); otherwise run ll_conv_cl + ll_rms_silu_cl.  ldo = Cout. */
+int ll_conv_cl_rms_ok(int H, int W, int Cin, int Cout, int KT, int KH, int upsample);
+int ll_conv_cl_rms(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res, ll_bf16* out,
+                   const ll_bf16* rms_gamma, ll_bf16* out_rms, int rms_silu, int T, int H, int W, int Cin, int Cout, int Kpad, int KT,
+                   int KH, int upsample, int ldo, ll_stream stream);
 
 /* RMS_norm over channels (+ SiLU) (wan/modules/vae.py:39-55,193-197) on channels-last rows with the reference's bf16
  * rounding points: n = bf16(||x||); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = silu(y) if do_silu. */

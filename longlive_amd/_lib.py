@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblonglive_hip.so")
 
-ABI_VERSION = 105      # include/longlive_hip.h: LL_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 106      # include/longlive_hip.h: LL_ABI_VERSION (tests/test_abi.py holds the two together)
 
 _p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -55,6 +55,8 @@ SIGNATURES = {
     "ll_flash_attn_qnorm_ok": [_i, _i],
     "ll_flash_attn_qnorm": [_p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _ll, _i, _i, _f, _p],
     "ll_conv_cl": [_p] * 6 + [_i] * 10 + [_p],
+    "ll_conv_cl_rms_ok": [_i] * 7,
+    "ll_conv_cl_rms": [_p] * 8 + [_i] * 11 + [_p],
     "ll_rms_silu_cl": [_p, _p, _p, _ll, _i, _i, _p],
     "ll_softmax_rows": [_p, _p, _i, _i, _i, _f, _p],
     "ll_vae_unscale_cl": [_p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -249,12 +249,109 @@ __device__ __forceinline__ void hl_wait_vm() {
   if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
+// RMS_norm (+ SiLU) over channels, channels-last rows of C in {96, 192, 384} (wan/modules/vae.py:39-55, 193-197):
+//   n = bf16(||x||_2); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = bf16(silu(y))
+// (the reference's bf16 rounding points).  G lanes per pixel (16 / 32 / 64), 8 channels per lane.
+// x / n for a pair with ONE reciprocal per lane: the steps of the IEEE-correct fp32 division the compiler emits (Newton step on the
+// reciprocal -- done by the caller, once --, q0 = x r, two residual corrections) without its operand pre-scaling, which only acts when
+// an exponent is beyond 2^+-96: the caller takes this path for n in [2^-60, 2^60] (and |x| <= n by construction), else the plain `/`.
+__device__ __forceinline__ f32x2 div_by_shared(f32x2 x, float n, float r1) {
+  const f32x2 nn = splat2(-n), rr = splat2(r1);
+  f32x2 q = x * rr;
+  f32x2 rem = __builtin_elementwise_fma(nn, q, x);
+  q = __builtin_elementwise_fma(rem, rr, q);
+  rem = __builtin_elementwise_fma(nn, q, x);
+  return __builtin_elementwise_fma(rem, rr, q);
+}
+
+
+// Fused form for the convolutions whose workgroup holds ALL channels of a pixel (Cout = 16 NCB, one n-tile): the convolution's own
+// epilogue -- v = bf16(acc + bias) [bf16(res + v)] -- followed by the RMS_norm (+ SiLU) the decoder applies to that tensor next
+// (ResidualBlock: conv -> RMS_norm -> SiLU -> conv, vae.py:193-220), with rms_silu_cl_kernel's rounding points:
+//   n = max(bf16(||v||_2), 1e-12); y = bf16(bf16(bf16(v / n) sqrt(C)) gamma); out2 = bf16(silu(y)).
+// A lane holds 4 channels of each of the NCB 16-channel blocks of pixel (b, fr); the pixel's other channels sit in the three lanes
+// with the same fr (fg = 0..3): the sum of squares is the lane's 4 NCB values in block order, then two xor shuffles -- another
+// order of the fp32 sum than the stand-alone kernel's (8 consecutive channels per lane), so n may differ in its last bf16 bit in
+// rare cases (tests/test_vae_gpu.py bounds the outputs at 1 ulp).  Y == nullptr: the un-normalised tensor is not needed, only Y2.
+template <int EPI, int NCB>
+__device__ __forceinline__ void conv_epilogue_rms(f32x4 (&acc)[NCB][2], bf16* __restrict__ Y, bf16* __restrict__ Y2, int M, int ldo,
+                                                  int mw, int fr, int fg, const EpiArgs& ea, const bf16* __restrict__ gamma,
+                                                  int do_silu, float sqrt_c) {
+  static_assert(EPI == LL_EPI_BIAS || EPI == LL_EPI_BIAS_RES, "convolution epilogues");
+  bf16x4 bv[NCB], gv[NCB];
+#pragma unroll
+  for (int a = 0; a < NCB; ++a) {
+    bv[a] = *reinterpret_cast<const bf16x4*>(ea.bias + a * 16 + fg * 4);
+    gv[a] = *reinterpret_cast<const bf16x4*>(gamma + a * 16 + fg * 4);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int m = mw + b * 16 + fr;
+    const int mc = m < M ? m : M - 1;
+    bf16x4 rv[NCB];
+    if (EPI == LL_EPI_BIAS_RES) {
+#pragma unroll
+      for (int a = 0; a < NCB; ++a) rv[a] = *reinterpret_cast<const bf16x4*>(ea.res + (size_t)mc * ldo + a * 16 + fg * 4);
+    }
+    float v[NCB][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int a = 0; a < NCB; ++a)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = rbf((float)acc[a][b][j] + (float)bv[a][j]);
+        if (EPI == LL_EPI_BIAS_RES) t = rbf((float)rv[a][j] + t);
+        v[a][j] = t;
+        ss += t * t;
+      }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float n = fmaxf(rbf(sqrtf(ss)), 1e-12f);
+    const bool tame = n >= 0x1p-60f && n <= 0x1p60f;
+    const float r0 = __builtin_amdgcn_rcpf(n);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-n, r0, 1.0f), r0, r0);
+    const f32x2 sc = splat2(sqrt_c), one = splat2(1.0f), nl2e = splat2(-1.4426950408889634f);
+#pragma unroll
+    for (int a = 0; a < NCB; ++a) {
+      unsigned ow[2], yw[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x2 x2;
+        x2.x = v[a][2 * h], x2.y = v[a][2 * h + 1];
+        ow[h] = pack2(x2);
+        f32x2 q;
+        if (tame) q = div_by_shared(x2, n, r1);
+        else q.x = x2.x / n, q.y = x2.y / n;
+        f32x2 g2;
+        g2.x = (float)gv[a][2 * h], g2.y = (float)gv[a][2 * h + 1];
+        f32x2 y = rbf2(rbf2(rbf2(q) * sc) * g2);
+        if (do_silu) {
+          f32x2 e = nl2e * y;
+          e.x = __builtin_amdgcn_exp2f(e.x);
+          e.y = __builtin_amdgcn_exp2f(e.y);
+          e = one + e;
+          e.x = __builtin_amdgcn_rcpf(e.x);
+          e.y = __builtin_amdgcn_rcpf(e.y);
+          y = y * e;
+        }
+        yw[h] = pack2(y);
+      }
+      if (m < M) {
+        const size_t off = (size_t)m * ldo + a * 16 + fg * 4;
+        if (Y) *reinterpret_cast<uint2*>(Y + off) = make_uint2(ow[0], ow[1]);
+        *reinterpret_cast<uint2*>(Y2 + off) = make_uint2(yw[0], yw[1]);
+      }
+    }
+  }
+}
+
 // NCB = 16-channel output blocks per workgroup: 6 (96 channels) or 1 (the 3-channel head, weights padded to 8 rows).
-template <int EPI, int NCB, int UP>
+template <int EPI, int NCB, int UP, bool RMS = false>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restrict__ x, const char* __restrict__ zero,
                                                            const char* __restrict__ Wt, bf16* __restrict__ Y, int T, int H,
                                                            int W, int Cin, int N, size_t wrow_bytes, int ldo, int tiles_w,
-                                                           int tiles_h, int ntn, EpiArgs ea) {
+                                                           int tiles_h, int ntn, EpiArgs ea, const bf16* __restrict__ rms_gamma = nullptr,
+                                                           bf16* __restrict__ Y2 = nullptr, int rms_silu = 0, float rms_sqrt_c = 0.f) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HW_ = hl_halo_w(UP), HPX = hl_halo_px(UP), HPIECES = hl_halo_pieces(UP);
   constexpr int HALO_B = HPIECES * 1024, WPIECES = 3 * NCB, WUNIT_B = WPIECES * 1024;
@@ -382,26 +479,12 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const char* __restric
     int hrow = h0 + 2 * wave + i;
     if (hrow >= Ho) continue;
     int m_row = (t * Ho + hrow) * Wo + w0;
-    gemm_epilogue<EPI, false, NCB, 2>(acc[i], Y, (t * Ho + hrow + 1) * Wo, N, ldo, m_row, n0, fr, fg, ea);
+    if (RMS) conv_epilogue_rms<EPI, NCB>(acc[i], Y, Y2, (t * Ho + hrow + 1) * Wo, ldo, m_row, fr, fg, ea, rms_gamma, rms_silu, rms_sqrt_c);
+    else gemm_epilogue<EPI, false, NCB, 2>(acc[i], Y, (t * Ho + hrow + 1) * Wo, N, ldo, m_row, n0, fr, fg, ea);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RMS_norm (+ SiLU) over channels, channels-last rows of C in {96, 192, 384} (wan/modules/vae.py:39-55, 193-197):
-//   n = bf16(||x||_2); y = bf16(bf16(bf16(x / max(n, 1e-12)) * sqrt(C)) * gamma); out = bf16(silu(y))
-// (the reference's bf16 rounding points).  G lanes per pixel (16 / 32 / 64), 8 channels per lane.
-// x / n for a pair with ONE reciprocal per lane: the steps of the IEEE-correct fp32 division the compiler emits (Newton step on the
-// reciprocal -- done by the caller, once --, q0 = x r, two residual corrections) without its operand pre-scaling, which only acts when
-// an exponent is beyond 2^+-96: the caller takes this path for n in [2^-60, 2^60] (and |x| <= n by construction), else the plain `/`.
-__device__ __forceinline__ f32x2 div_by_shared(f32x2 x, float n, float r1) {
-  const f32x2 nn = splat2(-n), rr = splat2(r1);
-  f32x2 q = x * rr;
-  f32x2 rem = __builtin_elementwise_fma(nn, q, x);
-  q = __builtin_elementwise_fma(rem, rr, q);
-  rem = __builtin_elementwise_fma(nn, q, x);
-  return __builtin_elementwise_fma(rem, rr, q);
-}
-
 template <int G>
 __global__ __launch_bounds__(256) void rms_silu_cl_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
                                                           bf16* __restrict__ out, long long pixels, int C, float sqrt_c,
@@ -534,14 +617,51 @@ __global__ __launch_bounds__(256) void cl_to_tchw_clamp_kernel(const bf16* __res
 static int g_conv_halo = 1;       // tuning key conv_halo: 0 = always the implicit-GEMM kernel
 void ll_set_conv_halo_internal(int v) { g_conv_halo = v; }
 
+// the halo-tile kernel takes this convolution (every 3x3x3 / upsampled 1x3x3 layer of the decoder at 60x104 ... 480x832 with
+// Cout % 96 == 0 or the <= 16-channel head): partial edge tiles are allowed when they waste < 30 % of the tile grid
+static bool conv_halo_takes(int H, int W, int Cin, int Cout, int KT, int KH, int upsample) {
+  const bool shape3 = KT == 3 && KH == 3 && !upsample, shape_up = KT == 1 && KH == 3 && upsample == 1;
+  const bool head = shape3 && Cout <= 16, wide = Cout % 96 == 0;
+  const int Ho = upsample ? 2 * H : H, Wo = upsample ? 2 * W : W;
+  const int tiles_w = (Wo + HL_TW - 1) / HL_TW, tiles_h = (Ho + HL_TH - 1) / HL_TH;
+  const bool fits = (long long)Ho * Wo * 10 >= 7ll * tiles_w * HL_TW * tiles_h * HL_TH && Wo % 2 == 0 && Ho % 2 == 0;
+  return g_conv_halo && (shape3 || shape_up) && (wide || head) && Cin % 32 == 0 && fits;
+}
+
+// 1 = ll_conv_cl_rms covers this convolution: the halo-tile kernel with ALL output channels of a pixel in one workgroup (Cout = 96)
+extern "C" int ll_conv_cl_rms_ok(int H, int W, int Cin, int Cout, int KT, int KH, int upsample) {
+  return (Cout == 96 && conv_halo_takes(H, W, Cin, Cout, KT, KH, upsample)) ? 1 : 0;
+}
+
+static int conv_cl_launch(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
+                          ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample, int ldo,
+                          ll_stream stream, const ll_bf16* rms_gamma, ll_bf16* out_rms, int rms_silu);
+
 extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
                           ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample,
                           int ldo, ll_stream stream) {
+  LL_REQUIRE(out != nullptr, "ll_conv_cl: null operand");
+  return conv_cl_launch(x, zero16, w, bias, res, out, T, H, W, Cin, Cout, Kpad, KT, KH, upsample, ldo, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int ll_conv_cl_rms(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
+                              ll_bf16* out, const ll_bf16* rms_gamma, ll_bf16* out_rms, int rms_silu, int T, int H, int W, int Cin,
+                              int Cout, int Kpad, int KT, int KH, int upsample, int ldo, ll_stream stream) {
+  LL_REQUIRE(rms_gamma != nullptr && out_rms != nullptr, "ll_conv_cl_rms: rms_gamma and out_rms are required (out may be NULL)");
+  LL_REQUIRE(ll_conv_cl_rms_ok(H, W, Cin, Cout, KT, KH, upsample), "ll_conv_cl_rms: this convolution is not covered (ask ll_conv_cl_rms_ok "
+             "first and run ll_conv_cl + ll_rms_silu_cl instead)");
+  LL_REQUIRE(ldo == Cout, "ll_conv_cl_rms: ldo=%d must equal Cout (both outputs are dense [pixels, Cout])", ldo);
+  return conv_cl_launch(x, zero16, w, bias, res, out, T, H, W, Cin, Cout, Kpad, KT, KH, upsample, ldo, stream, rms_gamma, out_rms, rms_silu);
+}
+
+static int conv_cl_launch(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16* w, const ll_bf16* bias, const ll_bf16* res,
+                          ll_bf16* out, int T, int H, int W, int Cin, int Cout, int Kpad, int KT, int KH, int upsample, int ldo,
+                          ll_stream stream, const ll_bf16* rms_gamma, ll_bf16* out_rms, int rms_silu) {
   LL_REQUIRE(Cin > 0 && Cin % 8 == 0, "ll_conv_cl: Cin=%d must be a multiple of 8", Cin);
   LL_REQUIRE(Cout > 0 && Cout % 8 == 0, "ll_conv_cl: Cout=%d must be a multiple of 8 (pad the weights)", Cout);
   LL_REQUIRE((KT == 1 || KT == 3) && (KH == 1 || KH == 3), "ll_conv_cl: taps must be 1 or 3 (got %d x %d x %d)", KT, KH, KH);
   LL_REQUIRE(upsample == 0 || (upsample == 1 && KT == 1 && KH == 3), "ll_conv_cl: upsample is 0, or 1 with a 1x3x3 kernel");
-  LL_REQUIRE(x && zero16 && w && bias && out, "ll_conv_cl: null operand");
+  LL_REQUIRE(x && zero16 && w && bias && (out || out_rms), "ll_conv_cl: null operand");
   const int taps = KT * KH * KH;
   const int nchunks = taps * (Cin / 8);
   LL_REQUIRE(Kpad % 64 == 0 && Kpad >= nchunks * 8 && Kpad < nchunks * 8 + 64, "ll_conv_cl: Kpad=%d does not match taps*Cin=%d", Kpad, nchunks * 8);
@@ -562,11 +682,9 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
   {
     // halo-tile kernel: 3x3x3 (96-channel tiles, or the <= 16-channel head) and the upsampled 1x3x3 (96-channel tiles)
     const bool shape3 = KT == 3 && KH == 3 && !upsample, shape_up = KT == 1 && KH == 3 && upsample == 1;
-    const bool head = shape3 && Cout <= 16, wide = Cout % 96 == 0;
-    // partial edge tiles are allowed when they waste < 30 % of the tile grid (60 x 104: 4 x 4 tiles, 24 %)
+    const bool head = shape3 && Cout <= 16;
     const int tiles_w = (Wo + HL_TW - 1) / HL_TW, tiles_h = (Ho + HL_TH - 1) / HL_TH;
-    const bool fits = (long long)Ho * Wo * 10 >= 7ll * tiles_w * HL_TW * tiles_h * HL_TH && Wo % 2 == 0 && Ho % 2 == 0;
-    if (g_conv_halo && (shape3 || shape_up) && (wide || head) && Cin % 32 == 0 && fits) {
+    if (conv_halo_takes(H, W, Cin, Cout, KT, KH, upsample)) {
       const int ntn_h = head ? 1 : Cout / 96;
       const long long nwg = (long long)T * tiles_h * tiles_w * ntn_h;
       LL_REQUIRE(nwg < (1ll << 31), "ll_conv_cl: too many tiles");
@@ -581,6 +699,20 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
                            (const char*)zero16, (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo,  \
                            tiles_w, tiles_h, ntn_h, ea);                                                               \
       } while (0)
+      if (rms_gamma != nullptr) {           // Cout == 96: one n-tile holds every channel of a pixel (ll_conv_cl_rms_ok)
+        const float sqc = sqrtf((float)Cout);
+#define HL_LAUNCH_RMS(E, UPV)                                                                                          \
+        do {                                                                                                           \
+          (void)ll_lds_attr((const void*)conv_halo_kernel<E, 6, UPV, true>, (int)HL_LDS(6, UPV));                      \
+          hipLaunchKernelGGL((conv_halo_kernel<E, 6, UPV, true>), hgrid, hblock, HL_LDS(6, UPV), s, (const char*)x,    \
+                             (const char*)zero16, (const char*)w, (bf16*)out, T, H, W, Cin, Cout, (size_t)Kpad * 2, ldo, \
+                             tiles_w, tiles_h, ntn_h, ea, (const bf16*)rms_gamma, (bf16*)out_rms, rms_silu, sqc);       \
+        } while (0)
+        if (shape_up) { if (res) HL_LAUNCH_RMS(LL_EPI_BIAS_RES, 1); else HL_LAUNCH_RMS(LL_EPI_BIAS, 1); }
+        else { if (res) HL_LAUNCH_RMS(LL_EPI_BIAS_RES, 0); else HL_LAUNCH_RMS(LL_EPI_BIAS, 0); }
+#undef HL_LAUNCH_RMS
+        return ll_check_launch("ll_conv_cl_rms(halo)");
+      }
       if (shape_up) {
         if (res) HL_LAUNCH(LL_EPI_BIAS_RES, 6, 1); else HL_LAUNCH(LL_EPI_BIAS, 6, 1);
       } else if (head) {
@@ -592,6 +724,7 @@ extern "C" int ll_conv_cl(const ll_bf16* x, const ll_bf16* zero16, const ll_bf16
       return ll_check_launch("ll_conv_cl(halo)");
     }
   }
+  LL_REQUIRE(rms_gamma == nullptr, "ll_conv_cl_rms: only the halo-tile kernel has the fused RMS_norm epilogue");
   const int nk = Kpad / 64;
   const bool nt3 = (Cout % 96 == 0) && (Cout % 128 != 0), nt1 = Cout <= 32;
   const int bn = nt1 ? 32 : nt3 ? 96 : 128;

@@ -648,6 +648,37 @@ def conv_cl(x, packed, bias, geo, upsample: bool = False, res=None, out=None):
     return out
 
 
+def conv_cl_rms_ok(geo, H: int, W: int, upsample: bool = False) -> bool:
+    """conv_cl_rms covers this convolution (the halo-tile kernel with every channel of a pixel in one workgroup: Cout = 96)."""
+    cin, cout, kpad, kt, kh = geo
+    return bool(_lib.load().ll_conv_cl_rms_ok(H, W, cin, cout, kt, kh, 1 if upsample else 0))
+
+
+def conv_cl_rms(x, packed, bias, geo, gamma, out_rms, silu: bool = True, upsample: bool = False, res=None, want_raw: bool = False):
+    """conv_cl + the RMS_norm (+ SiLU) of its result in ONE launch: out_rms [T, Ho, Wo, Cout] = rms_silu(conv(x) [+ res]) -- what
+    ResidualBlock feeds its next convolution (vae.py:193-220).  want_raw: also return the un-normalised tensor (the next block's
+    shortcut), else None.  Only where conv_cl_rms_ok(...)."""
+    cin, cout, kpad, kt, kh = geo
+    _chk(x, "x"); _chk(packed, "w"); _chk(bias, "bias"); _chk(gamma, "gamma"); _chk(out_rms, "out_rms")
+    hist = 2 if kt > 1 else 0
+    T, H, W, C = x.shape[0] - hist, x.shape[1], x.shape[2], x.shape[3]
+    assert T >= 1 and C == cin and packed.shape == (cout, kpad) and bias.numel() == cout and gamma.numel() == cout
+    Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
+    assert out_rms.shape == (T, Ho, Wo, cout) and out_rms.is_contiguous()
+    out = torch.empty(T, Ho, Wo, cout, dtype=bf16, device=x.device) if want_raw else None
+    if res is not None:
+        _chk(res, "res")
+        assert res.shape == out_rms.shape
+    lib = _lib.load()
+    t0 = timer.begin("conv") if timer is not None else None
+    _lib.check(lib.ll_conv_cl_rms(x[hist:].data_ptr(), zero_row(x.device).data_ptr(), packed.data_ptr(), bias.data_ptr(), _ptr(res),
+                                  _ptr(out), gamma.data_ptr(), out_rms.data_ptr(), 1 if silu else 0, T, H, W, cin, cout, kpad, kt, kh,
+                                  1 if upsample else 0, cout, _stream()), "ll_conv_cl_rms")
+    if timer is not None:
+        timer.end("conv", t0, 2.0 * T * Ho * Wo * cout * (kt * kh * kh * cin))
+    return out
+
+
 def rms_silu_cl(x, gamma, silu: bool = True, out=None):
     _chk(x, "x"); _chk(gamma, "gamma")
     C = x.shape[-1]

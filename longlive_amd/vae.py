@@ -14,6 +14,7 @@ is skipped, the 'Rep' branch of Resample.forward, vae.py:108-112) frames are pro
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -58,14 +59,25 @@ class _Conv:
         self._buf = buf
         return buf[2:]
 
-    def __call__(self, x: torch.Tensor, upsample: bool = False, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, upsample: bool = False, res: Optional[torch.Tensor] = None, rms=None,
+                 want_raw: bool = True) -> torch.Tensor:
+        """rms = (gamma, out_rms): the convolution's epilogue also writes rms_silu(result) into out_rms (the next convolution's input
+        buffer) -- one launch instead of two where ops.conv_cl_rms_ok says so, else the two launches; want_raw = False: the
+        un-normalised result is not needed (None is returned when the fused kernel ran)."""
         if not self.temporal:
-            return ops.conv_cl(x, self.w, self.b, self.geo, upsample=upsample, res=res)
-        if self._buf is None or x.data_ptr() != self._buf[2:].data_ptr():
-            self.input(x.shape[0], x.shape[1], x.shape[2], x.device).copy_(x)     # producer did not write in place
-        buf, self._buf = self._buf, None
-        y = ops.conv_cl(buf, self.w, self.b, self.geo, upsample=upsample, res=res)
-        self._hist = buf[-2:]
+            buf = x
+        else:
+            if self._buf is None or x.data_ptr() != self._buf[2:].data_ptr():
+                self.input(x.shape[0], x.shape[1], x.shape[2], x.device).copy_(x)     # producer did not write in place
+            buf, self._buf = self._buf, None
+        if rms is not None and ops.conv_cl_rms_ok(self.geo, x.shape[1], x.shape[2], upsample):
+            y = ops.conv_cl_rms(buf, self.w, self.b, self.geo, rms[0], rms[1], upsample=upsample, res=res, want_raw=want_raw)
+        else:
+            y = ops.conv_cl(buf, self.w, self.b, self.geo, upsample=upsample, res=res)
+            if rms is not None:
+                ops.rms_silu_cl(y, rms[0], out=rms[1])
+        if self.temporal:
+            self._hist = buf[-2:]
         return y
 
 
@@ -75,6 +87,7 @@ class WanVAEDecoderHIP(nn.Module):
 
     def __init__(self, cfg: Optional[VaeConfig] = None, device="cuda", chunk: int = 2):
         super().__init__()
+        self.fuse_rms = os.environ.get("LL_VAE_FUSE", "1") != "0"      # kernel A/B only: 0 = RMS_norm + SiLU as their own launches
         self.cfg = cfg or VaeConfig()
         self.dims, self.layers = vae_decoder_layout(self.cfg)
         self.chunk = max(1, int(chunk))
@@ -147,9 +160,12 @@ class WanVAEDecoderHIP(nn.Module):
         c1, c2 = self._convs[name + ".residual.2"], self._convs[name + ".residual.6"]
         h = self._convs[name + ".shortcut"](x) if (name + ".shortcut") in self._convs else x
         y = ops.rms_silu_cl(x, self._gamma[name + ".residual.0.gamma"], out=c1.input(T, H, W, x.device))
-        y = c1(y)
-        y = ops.rms_silu_cl(y, self._gamma[name + ".residual.3.gamma"], out=c2.input(T, H, W, x.device))
-        return c2(y, res=h)
+        y2 = c2.input(T, H, W, x.device)
+        if self.fuse_rms:
+            c1(y, rms=(self._gamma[name + ".residual.3.gamma"], y2), want_raw=False)  # conv -> RMS_norm -> SiLU in one launch where covered
+        else:
+            ops.rms_silu_cl(c1(y), self._gamma[name + ".residual.3.gamma"], out=y2)
+        return c2(y2, res=h)
 
     def _attn_block(self, x, name):                                      # AttentionBlock.forward (vae.py:240-262)
         a = self._attn[name]

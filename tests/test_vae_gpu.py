@@ -93,6 +93,43 @@ def test_conv_halo_and_implicit_gemm_kernels_agree(ops):
     assert_bf16_close(outs[0], outs[1], 1, 0.9, "halo vs implicit GEMM")
 
 
+@pytest.mark.parametrize("T,H,W,Cin,up,with_res,silu,want_raw", [
+    (2, 32, 64, 96, False, False, True, False),      # ResidualBlock: conv1 -> RMS_norm -> SiLU (the un-normalised tensor is not kept)
+    (1, 30, 52, 96, False, True, True, True),        # conv2 + shortcut -> next block's RMS_norm, partial edge tiles, both outputs
+    (2, 15, 26, 192, True, False, True, True),       # upsampled 1x3x3 (192 -> 96) feeding the first block of the 96-channel stage
+    (1, 16, 32, 96, False, False, False, True),      # RMS_norm without SiLU
+])
+def test_conv_cl_rms_is_conv_then_rms_silu(ops, T, H, W, Cin, up, with_res, silu, want_raw):
+    """ll_conv_cl_rms (the convolution's epilogue also applies the RMS_norm + SiLU that follows it, vae.py:193-220) against the two
+    launches it replaces: the un-normalised output bit-identical (same accumulators, same epilogue arithmetic), the normalised one
+    within 1 bf16 ulp (the sum of squares is taken in another order: 4 channels of each 16-block per lane instead of 8 consecutive)."""
+    Cout, KT = 96, (1 if up else 3)
+    x = hn("fx", (1, Cin, T + (2 if KT == 3 else 0), H, W))
+    w = hn("fw", (Cout, Cin, KT, 3, 3), 1.0 / math.sqrt(Cin * KT * 9))
+    g = hn("fg", (Cout,), 0.1, 1.0).to(DEV)
+    pk, pb, geo = ops.pack_conv_weight(w.to(DEV), hn("fb", (Cout,), 0.1).to(DEV))
+    assert ops.conv_cl_rms_ok(geo, H, W, up)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    res = hn("fr", (T, Ho, Wo, Cout)).to(DEV) if with_res else None
+    xin = to_cl(x).to(DEV)
+    raw = ops.conv_cl(xin, pk, pb, geo, upsample=up, res=res)
+    want = ops.rms_silu_cl(raw, g, silu=silu)
+    out2 = torch.full((T, Ho, Wo, Cout), float("nan"), dtype=bf, device=DEV)
+    got_raw = ops.conv_cl_rms(xin, pk, pb, geo, g, out2, silu=silu, upsample=up, res=res, want_raw=want_raw)
+    torch.cuda.synchronize()
+    if want_raw:
+        assert torch.equal(got_raw, raw)
+    else:
+        assert got_raw is None
+    assert_bf16_close(out2, want, 1, 0.98, f"conv + rms_silu fused, Cin={Cin} up={up} res={with_res}")
+    # not covered: another channel count / the implicit-GEMM shapes -> the predicate says so and the entry point refuses
+    pk2, pb2, geo2 = ops.pack_conv_weight(hn("fw2", (192, 192, 3, 3, 3)).to(DEV), torch.zeros(192, dtype=bf, device=DEV))
+    assert not ops.conv_cl_rms_ok(geo2, 16, 32)
+    with pytest.raises(RuntimeError):
+        ops.conv_cl_rms(torch.zeros(3, 16, 32, 192, dtype=bf, device=DEV), pk2, pb2, geo2, torch.ones(192, dtype=bf, device=DEV),
+                        torch.empty(1, 16, 32, 192, dtype=bf, device=DEV))
+
+
 def test_conv_cl_rejects_bad_shapes(ops):
     w = hn("w", (96, 96, 3, 3, 3)).to(DEV)
     pk, pb, geo = ops.pack_conv_weight(w, torch.zeros(96, dtype=bf, device=DEV))

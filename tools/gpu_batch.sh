@@ -174,6 +174,11 @@ for line in open(sys.argv[1]):
     print("%-12s %-12s %8.1f us %7s TF/s  sclk %6.0f MHz (xcd %s)  %6.0f W  ppt %.2f  %7.2f mJ/launch" % (r["lib"].split("/")[-2] if "/" in r["lib"] else r["lib"], r["load"], r["us_per_launch"], r["tflops"], r["sclk_mhz_avg"] or 0, ("%.0f-%.0f" % (min(x), max(x))) if x else "-", r["power_w_avg"] or 0, r["ppt_residency"] or 0, r["energy_mj_per_launch"]))
 PY
       ;;
+    vaeab)         # vaeab[=rounds]: VAE decoder alone (tools/vae_bench.py 9 2), fused conv + RMS_norm epilogues on / off (LL_VAE_FUSE), interleaved
+      n=${arg:-2}; rc=0
+      for i in $(seq 1 $n); do for t in 1 0; do
+        echo -n "[LL_VAE_FUSE=$t] "; LL_VAE_FUSE=$t timeout -k 10 200 python3 tools/vae_bench.py 9 2 2>/dev/null | tail -1 | cut -c1-200; r=${PIPESTATUS[0]}; dead $r && { rc=$r; break 2; }
+      done; done > >(tee -a $O/vaeab.txt); wait ;;
     stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
       timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
