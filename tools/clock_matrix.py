@@ -48,8 +48,16 @@ def main():
     xq, sx = ops.quantize_rows(x); hq, shid = ops.quantize_rows(hid)
     w1q, s1 = ops.quantize_rows(w1); w2q, s2 = ops.quantize_rows(w2)
     EG, ER = ops.EPI_BIAS_GELU, ops.EPI_BIAS_RES
+    wo, bo = hn("wo", (C, C), 0.03), hn("bo", (C,), 0.1)
+    ck, cv = hn("ck", (1, 512, H, D)), hn("cv", (1, 512, H, D), 0.5)
+    a2 = ao.view(L, C)
     loads = {
         "attn": (lambda: ops.flash_attn(q, kc, vc, [(0, LK)], out=ao), 35, 4.0 * L * LK * D * H),
+        "attn_hip": (lambda: ops.flash_attn(q, kc, vc, [(0, LK)], out=ao), -1, 4.0 * L * LK * D * H),      # attn_asm = 0: the HIP ping-pong kernel
+        "cross": (lambda: ops.flash_attn(q, ck, cv, [(0, 512)], out=ao), 35, 4.0 * L * 512 * D * H),
+        "o": (lambda: ops.gemm(a2, wo, bo, ER, out=o2, res=x), 35, 2.0 * L * C * C),
+        "o_hip": (lambda: ops.gemm(a2, wo, bo, ER, out=o2, res=x), 0, 2.0 * L * C * C),
+        "qkv_hip": (lambda: ops.gemm(x, wq, bq, 0, out=o3), 0, 2.0 * L * 3 * C * C),
         "ffn1": (lambda: ops.gemm(x, w1, b1, EG, out=o1), 35, 2.0 * L * FF * C),
         "ffn2": (lambda: ops.gemm(hid, w2, b2, ER, out=o2, res=x), 35, 2.0 * L * FF * C),
         "qkv": (lambda: ops.gemm(x, wq, bq, 0, out=o3), 35, 2.0 * L * 3 * C * C),
@@ -64,7 +72,8 @@ def main():
     libname = os.environ.get("LONGLIVE_HIP_LIB", "shipped")
     for name in a.loads.split(","):
         fn, asm, flops = loads[name]
-        tune("gemm_asm", asm)
+        tune("attn_asm", 0 if asm < 0 else 1)
+        tune("gemm_asm", 35 if asm < 0 else asm)
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -93,6 +102,7 @@ def main():
                    energy_mj_per_launch=round((t.get("power_w_avg") or 0) * us * 1e-3, 2))
         print(json.dumps(rec), flush=True)
     tune("gemm_asm", 35)
+    tune("attn_asm", 1)
 
 
 if __name__ == "__main__":

@@ -179,6 +179,8 @@ PY
       for i in $(seq 1 $n); do for t in 1 0; do
         echo -n "[LL_VAE_FUSE=$t] "; LL_VAE_FUSE=$t timeout -k 10 200 python3 tools/vae_bench.py 9 2 2>/dev/null | tail -1 | cut -c1-200; r=${PIPESTATUS[0]}; dead $r && { rc=$r; break 2; }
       done; done > >(tee -a $O/vaeab.txt); wait ;;
+    clockloads)    # clockloads=<load>,<load>...: tools/clock_matrix.py over the named loads only (shipped library)
+      timeout -k 10 200 python3 tools/clock_matrix.py --loads "$arg" > $O/clock_loads.jsonl 2> $O/clock_loads.err; rc=$?; echo "clockloads rc=$rc"; cut -c1-330 $O/clock_loads.jsonl ;;
     stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
       timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
