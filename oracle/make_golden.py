@@ -543,6 +543,76 @@ def gen_config2(ns):
     _save("config2_recache.pt", rr)
 
 
+def gen_config4(ns):
+    """BASELINE config 4 end to end at full depth: the REFERENCE's InteractiveCausalInferencePipeline.inference
+    (pipeline/interactive_causal_inference.py:108-432) at 30 layers, 60x104, T = 21, two prompts, switch at frame 12, `global_sink`
+    False (configs/longlive_interactive_inference.yaml): blocks 0-3 under p0 (identical to config 2's: same noise, same re-noise
+    draws), then `_recache_after_switch` (caches zeroed, ONE 12-frame forward under p1, sink rewritten), then blocks 4-6 under p1 on
+    the recached window (which rolls).  36 generator calls.  Stored: latents of frames 12..20, an 8192-element sample of every x0 after
+    the switch, x0 of three frames of the recache forward, 24 sampled K / V slots of layers 0 / 14 / 29 + end indices after the recache
+    and after every later context pass."""
+    cfg = synth.longlive_1_3b()
+    fs = cfg.frame_seqlen
+    T, nfb, SW = 21, 3, 12
+    sd = synth.synth_state_dict(cfg, seed=0)
+    M = build_ref_model(ns, cfg, sd, fs)
+    del sd
+    wr = build_ref_wrapper(ns, M)
+    table = {"p0": synth.synth_prompt_embeds(cfg, seed=1), "p1": synth.synth_prompt_embeds(cfg, seed=2)}
+    args = SimpleNamespace(model_kwargs=SimpleNamespace(local_attn_size=12, sink_size=3, timestep_shift=5.0),
+                           denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=nfb,
+                           context_noise=0, global_sink=False)
+    I = ns.interactive.InteractiveCausalInferencePipeline(args, "cpu", generator=wr, text_encoder=_fake_text_encoder(table), vae=_FakeVAE())
+    assert (I.num_transformer_blocks, I.frame_seq_length) == (30, fs)
+    noise = synth.synth_noise(cfg, T, seed=0)
+    S = 12 * fs
+    slots = sample_rows(S, CONFIG2_SLOTS)
+    samp = torch.linspace(0, nfb * 16 * cfg.lat_h * cfg.lat_w - 1, CONFIG2_NSAMPLE).round().long()
+    rec = dict(T=T, switch_frame=SW, slots=slots, sample_idx=samp, layers=list(CONFIG2_LAYERS), renoise_seed=43, noise_seed=0,
+               prompt_seeds=[1, 2], recache_frames=[0, 5, 11], calls=[], after=[])
+    orig_fwd = wr.forward
+
+    def kv_sample(kv):
+        return dict(k=[kv[l]["k"][0, slots].clone() for l in CONFIG2_LAYERS], v=[kv[l]["v"][0, slots].clone() for l in CONFIG2_LAYERS],
+                    idx=(int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"])))
+
+    def spy(*a, **k):
+        t1 = time.time()
+        out = orig_fwd(*a, **k)
+        n = len(rec["calls"])
+        nf = k["noisy_image_or_video"].shape[1]
+        c = dict(t=float(k["timestep"].flatten()[0]), current_start=int(k["current_start"]), frames=nf,
+                 recache=bool(k.get("sink_recache_after_switch", False)))
+        if nf == 12:                                   # the recache forward
+            c["x0_frames"] = out[1][:, rec["recache_frames"]].clone()
+            c["kv"] = kv_sample(k["kv_cache"])
+        elif c["current_start"] >= SW * fs:
+            c["x0_sample"] = out[1].flatten()[samp].clone()
+            if c["t"] == 0.0:
+                c["kv"] = kv_sample(k["kv_cache"])
+        rec["calls"].append(c)
+        print(f"  call {n} (start {c['current_start'] // fs}, {nf} frames, t={c['t']:.0f}): {time.time() - t1:.1f}s", flush=True)
+        return out
+
+    real_randn_like = torch.randn_like
+    wr.forward = spy
+    try:
+        torch.randn_like = _HashRandn(43)
+        t0 = time.time()
+        _, lat = I.inference(noise, text_prompts_list=[["p0"], ["p1"]], switch_frame_indices=[SW], return_latents=True)
+        print(f"config4 pipeline ({len(rec['calls'])} forwards): {time.time() - t0:.1f}s", flush=True)
+    finally:
+        torch.randn_like = real_randn_like
+        wr.forward = orig_fwd
+    assert len(rec["calls"]) == 36 and rec["calls"][20]["frames"] == 12
+    c2 = os.path.join(OUT, "config2_pipe.pt")
+    if os.path.exists(c2):                              # before the switch the run IS config 2's (same noise, prompt and draws)
+        assert torch.equal(lat[:, :SW], torch.load(c2)["latents"][:, :SW]), "blocks 0-3 must reproduce config 2's latents"
+        rec["prefix_equals_config2"] = True
+    rec["latents_after_switch"] = lat[:, SW:].clone()
+    _save("config4_pipe.pt", rec)
+
+
 def main(argv):
     from oracle import fast_hash
     fast_hash.install()                                # the same integers, ~100x faster on the CPU (host build of csrc/synth_hash.h)

@@ -550,6 +550,74 @@ def test_config2_switch_at_full_depth_vs_reference(real30, gs):
             assert e < (1e-2 if layer == 0 else 5e-2), (layer, nm, e)
 
 
+@pytest.mark.skipif(not (_have("config4_pipe.pt") and _have("config2_pipe.pt")), reason="golden missing")
+def test_config4_interactive_vs_reference_at_full_depth(real30):
+    """BASELINE config 4 END TO END at full depth against the reference's own InteractiveCausalInferencePipeline.inference
+    (oracle/make_golden.py::gen_config4: 30 layers, 60x104, T = 21, prompts p0 -> p1 at frame 12, `global_sink` false): OUR
+    interactive pipeline free-running on the MI355X -- blocks 0-3 under p0, the KV-recache forward (caches zeroed, 12 frames in one
+    forward under p1, sink rewritten), blocks 4-6 under p1 on the recached window as it rolls.  Compared: the generator-call sequence
+    (timestep, current_start, frames, recache flag) of all 36 calls; latents before the switch against config 2's golden (the
+    reference's run reproduces it bit for bit up to there) and after it against this one, per block; an 8192-element sample of every
+    x0 after the switch; 24 sampled K / V slots of layers 0 / 14 / 29 + end indices after the recache and after every later context
+    pass.  Bounds: rel-L2 <= 3e-2 / cosine >= 0.9995 per forward and per block, cache slots 1e-2 (layer 0) / 5e-2."""
+    from longlive_amd.pipeline import InteractiveCausalInferencePipeline
+    rec, rec2 = load_golden("config4_pipe.pt"), load_golden("config2_pipe.pt")
+    cfg, gen = real30
+    fs, SW = cfg.frame_seqlen, rec["switch_frame"]
+    prompts = {f"p{i}": {"prompt_embeds": synth.synth_prompt_embeds(cfg, seed=sd, device=DEV)} for i, sd in enumerate(rec["prompt_seeds"])}
+    I = InteractiveCausalInferencePipeline(_pipe_args(global_sink=False), DEV, generator=gen, text_encoder=lambda text_prompts: prompts[text_prompts[0]])
+    I.randn_like = TD.HashRandn(rec["renoise_seed"])
+    calls, orig = [], gen.forward
+    sl, samp = rec["slots"].to(DEV), rec["sample_idx"].to(DEV)
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        want = rec["calls"][len(calls)]
+        nf = k["noisy_image_or_video"].shape[1]
+        got = dict(t=float(k["timestep"].flatten()[0]), current_start=int(k["current_start"]), frames=nf,
+                   recache=bool(k.get("sink_recache_after_switch", False)))
+        assert abs(got["t"] - want["t"]) < 1e-3 and (got["current_start"], got["frames"], got["recache"]) == (want["current_start"], want["frames"], want["recache"]), (len(calls), got, {kk: want[kk] for kk in got})
+        row = dict(n=len(calls), **got)
+        if "x0_sample" in want and out is not None and out[1] is not None:
+            g = out[1].flatten()[samp].cpu()
+            row.update(rel=rel_l2(g, want["x0_sample"]), cos=cosine(g, want["x0_sample"]))
+        if "kv" in want:
+            torch.cuda.synchronize()                      # (a context pass may run on the pipeline's second stream)
+            kv = k["kv_cache"]
+            assert (int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"])) == tuple(want["kv"]["idx"]), (len(calls), want["kv"]["idx"])
+            row["kv"] = {}
+            for li, layer in enumerate(rec["layers"]):
+                for nm in ("k", "v"):
+                    a_, b_ = kv[layer][nm][0, sl].cpu(), want["kv"][nm][li]
+                    assert torch.equal(a_.float().abs().sum(dim=(1, 2)) == 0, b_.float().abs().sum(dim=(1, 2)) == 0), (len(calls), layer, nm, "slot occupancy")
+                    row["kv"][f"L{layer}.{nm}"] = rel_l2(a_, b_)
+        calls.append(row)
+        return out
+    gen.forward = spy
+    try:
+        _, lat = I.inference(synth.synth_noise(cfg, rec["T"], seed=rec["noise_seed"], device=DEV), text_prompts_list=[["p0"], ["p1"]],
+                             switch_frame_indices=[SW], return_latents=True)
+    finally:
+        gen.forward = orig
+    assert len(calls) == 36
+    for r in calls:
+        if "rel" in r:
+            print(f"config 4: call {r['n']} (frame {r['current_start'] // fs}, t={r['t']:.0f}): x0 sample relL2 {r['rel']:.2e} cos {r['cos']:.6f}")
+            assert r["rel"] < 3e-2 and r["cos"] > 0.9995, r
+        if "kv" in r:
+            print(f"config 4: call {r['n']} ({'recache' if r['frames'] == 12 else 'context pass'} at frame {r['current_start'] // fs}) cache slots: "
+                  + "  ".join(f"{k_} {v_:.1e}" for k_, v_ in r["kv"].items()))
+            for k_, v_ in r["kv"].items():
+                assert v_ < (1e-2 if k_.startswith("L0.") else 5e-2), (r["n"], k_, v_)
+    want_lat = torch.cat([rec2["latents"][:, :SW], rec["latents_after_switch"]], dim=1)
+    for blk in range(7):
+        a_, b_ = lat[:, 3 * blk: 3 * blk + 3].cpu(), want_lat[:, 3 * blk: 3 * blk + 3]
+        r_, c_ = rel_l2(a_, b_), cosine(a_, b_)
+        print(f"config 4: block {blk} ({'p0' if blk < 4 else 'p1, after the switch'}) latents relL2 {r_:.2e} cos {c_:.6f}")
+        assert r_ < 3e-2 and c_ > 0.9995, (blk, r_, c_)
+    assert calls[20]["frames"] == 12 and calls[20]["recache"]           # the switch took effect at block 4 (frame 12)
+
+
 def test_config3_60s_single_prompt_property(real30):
     """BASELINE config 3 at full length: 240 latent frames (960 pixel frames = 60 s), bf16, sliding KV cache + frame sink."""
     cfg, gen = real30
