@@ -49,6 +49,12 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf
 MFMA_I8_DENSE_PEAK_TOPS = 5000.0          # 2x the bf16 rate (v_mfma_i32_16x16x64_i8)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 PIXEL_FRAMES_PER_LATENT = 4               # VAE temporal stride (wan/configs/wan_t2v_1_3B.py:17)
+# Energy view (profiles/r05_clock_matrix.md): algorithmic FLOPs of one steady-state block (5 forwards x 30 layers: self-attention 538.27 G,
+# six block linears 390.4 G, cross-attention 14.7 G per layer-forward), the board's floor power (what an HBM-bound row kernel draws)
+# and the matrix pipe's own dynamic energy per bf16 FLOP (MFMA-only builds of the generated GEMM text, looped) -- committed figures.
+FLOP_PER_BLOCK = 141.5e12
+BOARD_FLOOR_W = 619.0
+MFMA_PJ_PER_FLOP = 0.43
 BASELINE_FPS = None                       # BASELINE.json "published": {} -> no number for this exact metric on MI355X
 METRIC = "generated frames/sec (832x480) LongLive-1.3B, frame-sink + short-window attention, 4 denoise steps + clean-context pass"
 WORKLOAD = ("LongLive-1.3B 832x480 (latent 16x60x104), 3-frame AR blocks at steady state: Lq=4680, Lk=18720 (sink 3 + window "
@@ -765,6 +771,21 @@ def run_replica(args, rank, world, local_rank, sync):
     return res
 
 
+def energy_view(elapsed_s: float, steps: int, telemetry) -> dict | None:
+    """What a block cost in joules over the timed region, and how far the path is from its POWER roofline: a block of nothing but its
+    MFMAs would need FLOP_PER_BLOCK x MFMA_PJ_PER_FLOP of dynamic energy; the board gives (regulated power - floor) of dynamic power."""
+    p = (telemetry or {}).get("power_w_avg")
+    if not p or steps <= 0:
+        return None
+    t = elapsed_s / steps
+    dyn = (p - BOARD_FLOOR_W) * t
+    mfma = FLOP_PER_BLOCK * MFMA_PJ_PER_FLOP * 1e-12
+    return {"j_per_block": p * t, "floor_w": BOARD_FLOOR_W, "dynamic_j_per_block": dyn, "mfma_only_j_per_block": mfma,
+            "power_roofline_frac": mfma / dyn if dyn > 0 else None,
+            "note": "floor_w and the matrix pipe's pJ / FLOP are committed figures of profiles/r05_clock_matrix.md (one device); power is this "
+                    "run's; bf16 pipeline only"}
+
+
 def _clock_power(res) -> dict:
     t = res.get("telemetry") or {}
     return dict(sclk_mhz_avg=t.get("sclk_mhz_avg"), power_w_avg=t.get("power_w_avg"))
@@ -791,6 +812,7 @@ def final_record(args, world, per_replica, res0):
                    "per_replica_power_w_avg": [r.get("power_w_avg") for r in sorted(per_replica, key=lambda r: r["rank"])]},
         "roofline": res0.get("roofline"), "cpu_baseline": res0.get("cpu_baseline"),
         "telemetry": res0.get("telemetry"),
+        "energy": energy_view(res0["elapsed"], args.steps, res0.get("telemetry")) if (args.quant == "none" and "elapsed" in res0) else None,
     }
     if res0.get("kernels") is not None:
         out["kernels"] = res0["kernels"]
