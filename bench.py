@@ -706,11 +706,12 @@ def run_replica(args, rank, world, local_rank, sync):
                 traffic = None
         trace_us, trace_src = None, None                       # the kernel trace of the same command, committed (begin -> end of every launch)
         try:
-            tp = os.path.join(ROOT, "profiles", "r05_kernel_summary.md")
+            import glob
+            tp = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_summary.md")))[-1]       # the latest round's committed trace
             for line in open(tp):
                 if "flash_attn_asm_kernel" in line and "(self" in line:
                     trace_us = float(line.split("|")[3])
-                    trace_src = ("profiles/r05_kernel_summary.md: rocprofv3 --kernel-trace of `bench.py --steps 3 --warmup 4` (tools/gpu_batch.sh trace), "
+                    trace_src = (f"profiles/{os.path.basename(tp)}: rocprofv3 --kernel-trace of `bench.py --steps 3 --warmup 4` (tools/gpu_batch.sh trace), "
                                  "all self-attention launches of its steady-state window; a committed figure, NOT collected in this run")
                     break
         except Exception:
