@@ -155,17 +155,25 @@ class WanVAEDecoderHIP(nn.Module):
         self._first = True
 
     # -- blocks ----------------------------------------------------------------------------------------------------
-    def _res_block(self, x, name):                                       # ResidualBlock.forward (vae.py:202-220)
+    def _res_block(self, x, name, pre: bool = False, nxt=None):           # ResidualBlock.forward (vae.py:202-220)
+        """pre: the producer of x already wrote rms_silu(x) into this block's first convolution's input buffer.  nxt = (gamma, conv) of
+        the RMS_norm + SiLU + convolution that consume this block's output next: written by conv2's epilogue (one launch where
+        ops.conv_cl_rms_ok, else conv + rms_silu) -- the un-normalised output is returned as well (the next block's shortcut)."""
         T, H, W, _ = x.shape
         c1, c2 = self._convs[name + ".residual.2"], self._convs[name + ".residual.6"]
         h = self._convs[name + ".shortcut"](x) if (name + ".shortcut") in self._convs else x
-        y = ops.rms_silu_cl(x, self._gamma[name + ".residual.0.gamma"], out=c1.input(T, H, W, x.device))
+        if pre:
+            y = c1._buf[2:] if c1.temporal else c1._buf
+        else:
+            y = ops.rms_silu_cl(x, self._gamma[name + ".residual.0.gamma"], out=c1.input(T, H, W, x.device))
         y2 = c2.input(T, H, W, x.device)
         if self.fuse_rms:
             c1(y, rms=(self._gamma[name + ".residual.3.gamma"], y2), want_raw=False)  # conv -> RMS_norm -> SiLU in one launch where covered
         else:
             ops.rms_silu_cl(c1(y), self._gamma[name + ".residual.3.gamma"], out=y2)
-        return c2(y2, res=h)
+        if nxt is None:
+            return c2(y2, res=h)
+        return c2(y2, res=h, rms=(nxt[0], nxt[1].input(T, H, W, x.device)), want_raw=True)
 
     def _attn_block(self, x, name):                                      # AttentionBlock.forward (vae.py:240-262)
         a = self._attn[name]
@@ -190,25 +198,48 @@ class WanVAEDecoderHIP(nn.Module):
             ops.gemm(o, a["wo"], a["bo"], epilogue=ops.EPI_BIAS_RES, res=xt, out=out[t].reshape(hw, C))
         return out
 
-    def _resample(self, x, name, mode):                                  # Resample.forward (vae.py:101-143)
+    def _resample(self, x, name, mode, nxt=None):                                  # Resample.forward (vae.py:101-143)
         if mode == "up3d" and not self._first:
             T, H, W, C = x.shape
             y = self._convs[name + ".time_conv"](x)                      # [T,H,W,2C]: two output frames per input frame
             x = y.view(T, H, W, 2, C).permute(0, 3, 1, 2, 4).reshape(2 * T, H, W, C).contiguous()   # vae.py:131-134 interleave
-        return self._convs[name + ".resample.1"](x, upsample=True)
+        conv = self._convs[name + ".resample.1"]
+        if nxt is None:
+            return conv(x, upsample=True)
+        return conv(x, upsample=True, rms=(nxt[0], nxt[1].input(x.shape[0], 2 * x.shape[1], 2 * x.shape[2], x.device)), want_raw=True)
+
+    def _consumer(self, i: int):
+        """(gamma, conv) of the RMS_norm + SiLU + convolution that read layer i's output next -- a residual block's first pair, or the
+        head's -- when the producer can write the normalised tensor itself; None: an attention block or a resample comes next."""
+        if not self.fuse_rms:
+            return None
+        if i + 1 == len(self.layers):
+            c = (self._gamma["decoder.head.0.gamma"], self._convs["decoder.head.2"])
+        elif self.layers[i + 1][0] == "res":
+            nl = self.layers[i + 1]
+            c = (self._gamma[nl[1] + ".residual.0.gamma"], self._convs[nl[1] + ".residual.2"])
+        else:
+            return None
+        return c if c[1].temporal else None           # (the consumer's input buffer is remembered only by temporal convolutions)
 
     def _decoder_step(self, x):                                          # Decoder3d.forward (vae.py:423-472)
         x = self._convs["decoder.conv1"](x)
-        for L in self.layers:
+        pre = False
+        for i, L in enumerate(self.layers):
+            nxt = self._consumer(i)
             if L[0] == "res":
-                x = self._res_block(x, L[1])
+                x = self._res_block(x, L[1], pre, nxt)
             elif L[0] == "attn":
-                x = self._attn_block(x, L[1])
+                x, nxt = self._attn_block(x, L[1]), None
             else:
-                x = self._resample(x, L[1], L[0])
+                x = self._resample(x, L[1], L[0], nxt)
+            pre = nxt is not None
         head = self._convs["decoder.head.2"]
-        x = ops.rms_silu_cl(x, self._gamma["decoder.head.0.gamma"], out=head.input(x.shape[0], x.shape[1], x.shape[2], x.device))
-        return head(x)                          # [T', H, W, 8] (3 channels + padding)
+        if pre:
+            y = head._buf[2:] if head.temporal else head._buf
+        else:
+            y = ops.rms_silu_cl(x, self._gamma["decoder.head.0.gamma"], out=head.input(x.shape[0], x.shape[1], x.shape[2], x.device))
+        return head(y)                          # [T', H, W, 8] (3 channels + padding)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, keep_cache: bool = False) -> torch.Tensor:
