@@ -181,6 +181,12 @@ PY
       done; done > >(tee -a $O/vaeab.txt); wait ;;
     clockloads)    # clockloads=<load>,<load>...: tools/clock_matrix.py over the named loads only (shipped library)
       timeout -k 10 200 python3 tools/clock_matrix.py --loads "$arg" > $O/clock_loads.jsonl 2> $O/clock_loads.err; rc=$?; echo "clockloads rc=$rc"; cut -c1-330 $O/clock_loads.jsonl ;;
+    sweep)         # sweep=<key>:<v1>,<v2>,...[/rounds]: bench.py (short form) under LL_TUNING=<key>=<v>, every value in every round (interleaved)
+      spec=$(echo "$arg" | cut -d/ -f1); n=$(echo "$arg" | cut -d/ -f2); [ "$n" = "$spec" ] && n=2; key=${spec%%:*}; vals=$(echo "${spec#*:}" | tr ',' ' '); rc=0
+      for i in $(seq 1 $n); do for v in $vals; do
+        LL_TUNING=$key=$v timeout -k 10 400 python3 bench.py --steps 14 --warmup 4 --no-extras --no-cpu-baseline --no-kernel-timer > $O/sweep_${key}_${v}_$i.json 2> $O/sweep_$i.err; rc=$?; dead $rc && break 2
+        echo -n "[$key=$v] "; benchline $O/sweep_${key}_${v}_$i.json
+      done; done > >(tee -a $O/sweep.txt); wait ;;
     stealprobe)    # synthetic upper bound of dynamic work stealing between XCDs (tools/xcd_balance_probe.hip, section "steal")
       timeout -k 10 300 ./tools/xcd_balance_probe steal > $O/stealprobe.txt 2>&1; rc=$?; echo "stealprobe rc=$rc"; cat $O/stealprobe.txt | cut -c1-260 ;;
     *) echo "unknown step $step"; rc=1 ;;
